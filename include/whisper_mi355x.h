@@ -1,0 +1,169 @@
+/*
+ * whisper_mi355x.h -- C ABI of libwhisper_mi355x.so, the MI355X (gfx950) drop-in for the
+ * two native halves of tanmayb123/OpenAI-Whisper-CoreML's hot path:
+ *
+ *   boundary #1  the Rust `stft` staticlib          (stft/src/lib.rs:110-122, bridge.h:11)
+ *   boundary #2  the CoreML encoder/decoder classes (Whisper/Whisper/Whisper.swift:17-40,
+ *                contract fixed by whisper_to_cml.py:10-43)
+ *
+ * Plain C: pointers, sizes, ints.  No torch / C++ types cross this boundary.  Every
+ * function except generate_spectrogram returns an int status (WM_OK == 0) and never
+ * aborts or throws across the FFI; wm_last_error() returns the message for the calling
+ * thread.  A wm_ctx is not thread-safe; distinct contexts are independent.
+ *
+ * All pointers are HOST pointers unless the argument is documented "mem-space
+ * selectable", in which case `mem` says where it lives (WM_MEM_HOST / WM_MEM_DEVICE).
+ */
+#ifndef WHISPER_MI355X_H
+#define WHISPER_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status codes --- */
+enum {
+    WM_OK = 0,
+    WM_ERR_INVALID = 1,   /* bad argument (null, size, dtype, dims)                     */
+    WM_ERR_HIP = 2,       /* a HIP runtime call failed / no gfx950 device               */
+    WM_ERR_STATE = 3,     /* call order (weights not finalised, ctx has no model, ...)  */
+    WM_ERR_IO = 4,        /* weight file unreadable / malformed                         */
+    WM_ERR_NOMEM = 5
+};
+
+typedef enum { WM_I16 = 0, WM_F32 = 1, WM_F64 = 2, WM_BF16 = 3 } wm_dtype;
+typedef enum { WM_MEM_HOST = 0, WM_MEM_DEVICE = 1 } wm_mem;
+
+/* Model dimensions: the fields of openai-whisper's ModelDimensions, i.e. what
+ * whisper.load_model(...) at whisper_to_cml.py:7 fixes for the exported graphs. */
+typedef struct wm_dims {
+    int32_t n_mels;        /* 80 (128 for large-v3)                                     */
+    int32_t n_audio_ctx;   /* 1500                                                      */
+    int32_t n_audio_state; /* d                                                         */
+    int32_t n_audio_head;
+    int32_t n_audio_layer;
+    int32_t n_vocab;       /* 51865 (51864 *.en, 51866 large-v3)                        */
+    int32_t n_text_ctx;    /* 448                                                       */
+    int32_t n_text_state;
+    int32_t n_text_head;
+    int32_t n_text_layer;
+} wm_dims;
+
+typedef struct wm_ctx wm_ctx;
+
+/* ------------------------------------------------------- boundary #1: the front end --- */
+
+/* EXACT replacement for the reference's only native symbol:
+ *   Whisper/Whisper/bridge.h:11      void generate_spectrogram(double *, double *);
+ *   stft/src/lib.rs:110-122          #[no_mangle] pub extern fn generate_spectrogram(...)
+ * arg0: 480400 f64, caller-owned and MUTATED exactly as lib.rs:34-40,113 does (elements
+ *       [0,200) and [480200,480400) are overwritten with the reflected samples);
+ * arg1: 240000 f64, row-major [80][3000] (lib.rs:116-121).
+ * Lengths are implicit, nothing is retained, the symbol is re-entrant.  Runs the f64
+ * kernels on device $WM_DEVICE (default 0).  Like the reference (unwrap -> panic ->
+ * abort, lib.rs:45,85-87,106) it cannot report an error: on a HIP failure it prints the
+ * reason to stderr and abort()s -- there is no CPU fallback. */
+void generate_spectrogram(double *audio, double *output);
+
+/* Batched, typed, error-returning form of the same computation (lib.rs:49-102).
+ *   pcm   : [n_chunks][480000] samples, dtype WM_I16 (x = s/32768), WM_F32 or WM_F64;
+ *           mem-space selectable.  (No +200 padding: the reflect of lib.rs:34-40 is done
+ *           by index arithmetic on device.)
+ *   n_mels: 80 (the reference's m80.npy filterbank, bit-exact) or 128 (slaney filters
+ *           generated as openai-whisper's mel_128, for large-v3).
+ *   out   : [n_chunks][n_mels][3000], dtype WM_F64 (f64 arithmetic end to end: the
+ *           ABI-exact path) or WM_F32 (f32 arithmetic: the fast path); mem-space
+ *           selectable (same `mem` as pcm). */
+int wm_logmel(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int n_chunks, int n_mels,
+              void *out, wm_dtype out_dtype, wm_mem mem);
+
+/* --------------------------------------------------------- context / weight loading --- */
+
+/* Front-end-only context (no model): enough for wm_logmel. */
+int wm_create_frontend(int device, wm_ctx **out);
+
+/* Model context with uninitialised weights ( == Whisper.init, Whisper.swift:17-21, minus
+ * the load).  Fill with wm_set_tensor / wm_load_weights / wm_init_synthetic, then
+ * wm_finalize. */
+int wm_create(const wm_dims *dims, int device, wm_ctx **out);
+
+/* Set one parameter from host f32 data.  Names are openai-whisper state-dict keys, e.g.
+ * "encoder.conv1.weight", "encoder.blocks.0.attn.query.weight",
+ * "decoder.token_embedding.weight" (SURVEY.md 8f row 2).  n_elems must match. */
+int wm_set_tensor(wm_ctx *ctx, const char *name, const float *data, size_t n_elems);
+/* Read a parameter back as f32 (the value the kernels use, i.e. after bf16 rounding for
+ * matrix weights). */
+int wm_get_tensor(wm_ctx *ctx, const char *name, float *data, size_t n_elems);
+/* Flat weight file written by openai-whisper-coreml_amd/weights.py (format in DESIGN.md). */
+int wm_load_weights(wm_ctx *ctx, const char *path);
+/* Deterministic synthetic weights generated ON DEVICE (hash-based, approx N(0, std^2));
+ * identical values to weights.synthetic_state_dict(dims, seed) on the host. */
+int wm_init_synthetic(wm_ctx *ctx, uint64_t seed);
+/* Freeze weights: fuse QKV, permute conv taps, precompute tables.  Required before any
+ * model call. */
+int wm_finalize(wm_ctx *ctx);
+void wm_destroy(wm_ctx *ctx);
+
+const char *wm_last_error(void);
+int wm_get_dims(const wm_ctx *ctx, wm_dims *out);
+
+/* ---------------------------------------------------------- boundary #2: the model --- */
+
+/* == encoderModel.prediction(x_1:).var_1385 (Whisper.swift:29; whisper_to_cml.py:10-23).
+ *   mel: f32 [B][n_mels][3000]  ->  xa: f32 [B][n_audio_ctx][n_audio_state].
+ * Both mem-space selectable (same `mem`). */
+int wm_encode(wm_ctx *ctx, const float *mel, int B, float *xa, wm_mem mem);
+
+/* == decoderModel.prediction(x_1:xa:).var_2217 (Whisper.swift:36; whisper_to_cml.py:25-43),
+ * generalised from T == 1 to a T-token prefix (stateless: offset 0, no cache is kept).
+ *   tokens: i32 [B][T];  xa: f32 [B][n_audio_ctx][d];  logits: f32 [B][T][n_vocab]. */
+int wm_decode_logits(wm_ctx *ctx, const int32_t *tokens, int B, int T, const float *xa,
+                     float *logits, wm_mem mem);
+
+/* == Whisper.decode (Whisper.swift:33-40): one decoder step on <|startoftranscript|>
+ * (id `sot`, 50258 in the reference), arg-max over logits[lang_first .. lang_last]
+ * (50259...50357 in the reference), FIRST maximal element wins (Swift max(by:)).
+ *   lang_idx: i32 [B], index into Whisper.LANGUAGES. */
+int wm_detect_language(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first,
+                       int32_t lang_last, int32_t *lang_idx, wm_mem mem);
+
+/* New surface asked for by BASELINE.json (not in the reference): front end + encoder +
+ * KV-cached greedy decode of B independent 30 s chunks.
+ *   pcm        : [B][480000], dtype WM_I16 / WM_F32 / WM_F64, mem-space selectable;
+ *   prompt     : i32 [n_prompt] initial tokens (e.g. {sot, lang, transcribe, notimestamps});
+ *   max_new    : tokens to generate per chunk (<= n_text_ctx - n_prompt);
+ *   eot        : stop token; pass -1 to suppress stopping (fixed-length benchmark decode);
+ *   tokens_out : i32 [B][max_new] (host), padded with `eot` after a chunk stops;
+ *   lens_out   : i32 [B] (host) generated length per chunk. */
+int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int B,
+                         const int32_t *prompt, int n_prompt, int max_new, int32_t eot,
+                         int32_t *tokens_out, int32_t *lens_out, wm_mem mem);
+
+/* ------------------------------------------------------------ device memory helpers --- */
+/* For callers that keep inputs resident in HBM (bench.py; a Swift host would use them to
+ * avoid the 5.7 MB/chunk PCIe round trip of the reference ABI). */
+int wm_dev_malloc(wm_ctx *ctx, size_t bytes, void **dptr);
+int wm_dev_free(wm_ctx *ctx, void *dptr);
+int wm_dev_upload(wm_ctx *ctx, void *dptr, const void *host, size_t bytes);
+int wm_dev_download(wm_ctx *ctx, void *host, const void *dptr, size_t bytes);
+int wm_sync(wm_ctx *ctx);
+
+/* -------------------------------------------------------------------- measurement --- */
+/* Per-kernel-family HIP-event timing on the context's stream.  When enabled, every launch
+ * of a profiled kernel family is bracketed by hipEventRecord on the launch stream; the
+ * totals are read back with wm_profile_get (which synchronises). */
+int wm_profile_enable(wm_ctx *ctx, int on);
+int wm_profile_reset(wm_ctx *ctx);
+/* Writes a JSON object {"family": {"ms": total_ms, "n": launches}, ...} into buf. */
+int wm_profile_json(wm_ctx *ctx, char *buf, size_t buf_bytes);
+/* Wall-clock stage split of the last wm_transcribe_greedy call, in ms (HIP events):
+ * [0] front end, [1] encoder + cross-KV projection, [2] decode loop. */
+int wm_last_stage_ms(wm_ctx *ctx, float out3[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WHISPER_MI355X_H */

@@ -1,0 +1,92 @@
+"""hipcc build recipe for libwhisper_mi355x.so (gfx950 only, built IN-TREE).
+
+    python openai-whisper-coreml_amd/build.py [--force]
+
+Each translation unit is compiled to an object next to its source (build/ is git-ignored,
+the final .so too) and linked with hipcc.  Cross-compiles without a GPU.
+"""
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
+LIB = os.path.join(HERE, "libwhisper_mi355x.so")
+HOST_BIN = os.path.join(HERE, "host", "lid_main")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-I", os.path.join(ROOT, "include")]
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def _deps_mtime():
+    t = 0.0
+    for d in (CSRC, os.path.join(ROOT, "include")):
+        for f in os.listdir(d):
+            if f.endswith((".h", ".inc", ".hpp")):
+                t = max(t, os.path.getmtime(os.path.join(d, f)))
+    return t
+
+
+def _compile(src, force, hdr_t):
+    obj = os.path.join(OBJ, src + ".o")
+    s = os.path.join(CSRC, src)
+    if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(s)
+            and os.path.getmtime(obj) >= hdr_t):
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", s, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj, True
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_t = _deps_mtime()
+    srcs = sources()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(lambda s: _compile(s, force, hdr_t), srcs))
+    objs = [o for o, _ in res]
+    if any(c for _, c in res) or not os.path.exists(LIB) or force:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [
+            "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("built", LIB)
+    elif verbose:
+        print("up to date:", LIB)
+    return LIB
+
+
+def build_host(force=False, verbose=True):
+    """C++ host harness (the stand-in for the Swift caller)."""
+    src = os.path.join(HERE, "host", "lid_main.cpp")
+    if not os.path.exists(src):
+        return None
+    if (not force and os.path.exists(HOST_BIN)
+            and os.path.getmtime(HOST_BIN) >= os.path.getmtime(src)):
+        return HOST_BIN
+    cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", HOST_BIN, "-ldl"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("host build failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built", HOST_BIN)
+    return HOST_BIN
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    build_host(force="--force" in sys.argv)

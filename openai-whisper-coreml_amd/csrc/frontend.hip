@@ -1,0 +1,373 @@
+// frontend.hip -- log-mel front end for gfx950 (replaces the Rust `stft` crate,
+// /root/reference/stft/src/lib.rs:22-122).
+//
+// Per 30 s chunk:  reflect-index (lib.rs:34-40) -> 3000 frames, hop 160, window 400
+// (lib.rs:52) -> periodic Hann (lib.rs:26,43) -> 400-point real DFT (lib.rs:44-45) ->
+// power (lib.rs:54) -> mel projection (lib.rs:60-69) -> log10(max(.,1e-10)) (lib.rs:71-79)
+// -> per-chunk max (lib.rs:82-88) -> (max(x, gmax-8)+4)/4 (lib.rs:91-99), output
+// [n_mels][3000] row-major (lib.rs:116-121).
+//
+// Two arithmetic types from one template:
+//   double : the ABI-exact path (generate_spectrogram; <= 1e-9 abs vs the f64 oracle)
+//   float  : the fast path      (<= 1e-4 abs vs the f64 oracle)
+//
+// Kernel 1 (logmel_stage1): one workgroup owns FPB = 16*WPB consecutive frames of one
+// chunk.  The PCM span those frames cover is staged ONCE in LDS (coalesced HBM reads,
+// every sample read from HBM once per workgroup instead of 2.5x), with the reflect pad
+// done by index arithmetic.  The DFT uses the window symmetry w[n] == w[400-n], w[0]==0:
+//     Re X[k] =  sum_{n=1..200} w[n] (x[n] + x[400-n]) cos(2 pi k n/400)   (n=200 once)
+//     Im X[k] = -sum_{n=1..199} w[n] (x[n] - x[400-n]) sin(2 pi k n/400)
+// i.e. two [16 frames x 200] x [200 x 208] products per wave, issued on the matrix
+// pipe with the exact-f32 / f64 MFMA (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64:
+// an fmaf chain, no reduced precision), A operand built on the fly from the LDS span, B
+// operand = the L2-resident twiddle table.  Power -> LDS -> banded mel (the filterbank is
+// 97.6% zeros; summing the non-zero band in ascending k equals the reference's dense
+// ascending-k sum exactly) -> log10 -> store + per-chunk atomic max.
+// Kernel 2 (logmel_stage2): dynamic-range clamp + affine, in place.
+#include "wm_internal.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+namespace {
+
+constexpr int NJT = 13;          // 13 * 16 = 208 >= 201 bins
+constexpr int TW_COLS = NJT * 16;
+constexpr int PW_STRIDE = 209;   // odd stride: conflict-free column walks
+
+template <typename T>
+struct Acc;
+template <>
+struct Acc<float> {
+    typedef __attribute__((ext_vector_type(4))) float type;
+};
+template <>
+struct Acc<double> {
+    typedef __attribute__((ext_vector_type(4))) double type;
+};
+
+__device__ __forceinline__ Acc<float>::type mfma4(float a, float b, Acc<float>::type c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ Acc<double>::type mfma4(double a, double b, Acc<double>::type c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+// C/D row of accumulator register r for this lane (col is lane & 15 for both types).
+__device__ __forceinline__ int acc_row(float, int lane, int r) { return (lane >> 4) * 4 + r; }
+__device__ __forceinline__ int acc_row(double, int lane, int r) { return (lane >> 4) + 4 * r; }
+
+__device__ __forceinline__ float log10_t(float x) { return log10f(x); }
+__device__ __forceinline__ double log10_t(double x) { return log10(x); }
+
+// Monotone encodings so an unsigned atomicMax orders floating-point values.
+__device__ __forceinline__ unsigned long long enc_max(float v) {
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return (unsigned long long)u;
+}
+__device__ __forceinline__ unsigned long long enc_max(double v) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ void dec_max(unsigned long long e, float *out) {
+    unsigned u = (unsigned)e;
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    *out = __uint_as_float(u);
+}
+__device__ __forceinline__ void dec_max(unsigned long long e, double *out) {
+    unsigned long long u = (e & 0x8000000000000000ull) ? (e & 0x7fffffffffffffffull) : ~e;
+    *out = __longlong_as_double((long long)u);
+}
+
+template <typename T>
+__device__ __forceinline__ T load_sample(const void *pcm, int dtype, size_t idx) {
+    if (dtype == WM_I16) return (T)((const short *)pcm)[idx] * (T)(1.0 / 32768.0);
+    if (dtype == WM_F32) return (T)((const float *)pcm)[idx];
+    return (T)((const double *)pcm)[idx];
+}
+
+// LDS address of span sample p (p = local_frame * 160 + n): one pad word per 160 samples
+// so that the 16 frames a wave reads at the same n fall in different banks.
+__device__ __forceinline__ int span_addr(int frame, int n) { return frame * 161 + n + n / 160; }
+
+template <typename T, int WPB>
+__global__ __launch_bounds__(WPB * 64) void logmel_stage1(
+    const void *__restrict__ pcm, int pcm_dtype, int n_mels, const T *__restrict__ cosT,
+    const T *__restrict__ sinT, const T *__restrict__ win, const int *__restrict__ band_start,
+    const int *__restrict__ band_len, const float *__restrict__ band_w, T *__restrict__ out,
+    unsigned long long *__restrict__ gmax, int blocks_per_chunk) {
+    constexpr int FPB = 16 * WPB;
+    constexpr int SPAN = (FPB - 1) * WM_HOP + WM_N_FFT;
+    constexpr int SPAN_LDS = SPAN + SPAN / 160 + 4;
+    __shared__ T xs[SPAN_LDS];
+    __shared__ T pw[WPB][16][PW_STRIDE];
+
+    const int chunk = blockIdx.x / blocks_per_chunk;
+    const int f0 = (blockIdx.x % blocks_per_chunk) * FPB;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    // ---- stage the PCM span (reflect pad by index; lib.rs:34-40) -----------------------
+    const size_t chunk_base = (size_t)chunk * WM_N_SAMPLES;
+    for (int i = tid; i < SPAN; i += WPB * 64) {
+        int n = f0 * WM_HOP + i - 200;                     // index into the unpadded chunk
+        if (n < 0) n = -n;                                 // a[i] = a[400 - i]
+        if (n >= WM_N_SAMPLES) n = 2 * (WM_N_SAMPLES - 1) - n;  // a[j] = a[200 + (N-2) - i]
+        if (n < 0) n = 0;                                  // only for masked frames >= 3000
+        xs[i + i / 160] = load_sample<T>(pcm, pcm_dtype, chunk_base + n);
+    }
+    __syncthreads();
+
+    // ---- DFT of 16 frames per wave on the matrix pipe ------------------------------------
+    typedef typename Acc<T>::type acc_t;
+    acc_t accC[NJT], accS[NJT];
+#pragma unroll
+    for (int j = 0; j < NJT; ++j) {
+        accC[j] = (acc_t){0, 0, 0, 0};
+        accS[j] = (acc_t){0, 0, 0, 0};
+    }
+    const int fr = wave * 16 + (lane & 15);  // A row: frame within the block
+    const int kq = lane >> 4;                // A col / B row within the 4-deep k step
+    const int col = lane & 15;
+    for (int kk = 0; kk < 50; ++kk) {
+        const int n = 1 + 4 * kk + kq;  // 1..200
+        const T x1 = xs[span_addr(fr, n)];
+        const T x2 = xs[span_addr(fr, WM_N_FFT - n)];
+        const T w = win[n];
+        const T a_c = w * ((n == 200) ? x1 : (x1 + x2));
+        const T a_s = w * (x1 - x2);
+        const T *crow = cosT + (size_t)(n - 1) * TW_COLS + col;
+        const T *srow = sinT + (size_t)(n - 1) * TW_COLS + col;
+#pragma unroll
+        for (int j = 0; j < NJT; ++j) {
+            accC[j] = mfma4(a_c, crow[j * 16], accC[j]);
+            accS[j] = mfma4(a_s, srow[j * 16], accS[j]);
+        }
+    }
+    // power (lib.rs:54) -> LDS, [frame][bin]
+#pragma unroll
+    for (int j = 0; j < NJT; ++j) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const T re = accC[j][r], im = accS[j][r];
+            pw[wave][acc_row(T(0), lane, r)][j * 16 + col] = re * re + im * im;
+        }
+    }
+    __syncthreads();
+
+    // ---- banded mel + log10 + per-chunk max (lib.rs:60-88) -------------------------------
+    const int frame = f0 + wave * 16 + (lane & 15);
+    const bool live = frame < WM_N_FRAMES;
+    T vmax = (T)-1e30;
+    for (int m = lane >> 4; m < n_mels; m += 4) {
+        const int ks = band_start[m], kl = band_len[m];
+        const float *wrow = band_w + m * WM_MEL_MAXW;
+        T s = 0;
+        for (int t = 0; t < kl; ++t) s += pw[wave][lane & 15][ks + t] * (T)wrow[t];
+        s = (s > (T)1e-10) ? s : (T)1e-10;  // f64::max(1e-10): NaN -> 1e-10
+        const T v = log10_t(s);
+        if (live) {
+            out[((size_t)chunk * n_mels + m) * WM_N_FRAMES + frame] = v;
+            vmax = (v > vmax) ? v : vmax;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T o = __shfl_xor(vmax, off);
+        vmax = (o > vmax) ? o : vmax;
+    }
+    if (lane == 0 && vmax > (T)-1e29) atomicMax(gmax + chunk, enc_max(vmax));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void logmel_stage2(T *__restrict__ io,
+                                                     const unsigned long long *__restrict__ gmax,
+                                                     int per_chunk, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        T g;
+        dec_max(gmax[i / per_chunk], &g);
+        const T fl = g - (T)8.0;
+        T x = io[i];
+        x = (x > fl) ? x : fl;         // x.max(gmax - 8.0)   lib.rs:96
+        io[i] = (x + (T)4.0) / (T)4.0; // (.. + 4.0) / 4.0
+    }
+}
+
+template <typename T>
+int upload(T **dptr, const std::vector<T> &h, hipStream_t s) {
+    WM_HIP(hipMalloc((void **)dptr, h.size() * sizeof(T)));
+    WM_HIP(hipMemcpyAsync(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    WM_HIP(hipStreamSynchronize(s));
+    return WM_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ mel filterbanks -----
+static const float kMel80[80 * 201] = {
+#include "mel80.inc"
+};
+const float *wm_mel80_table() { return kMel80; }
+
+// librosa.filters.mel(sr=16000, n_fft=400, n_mels, htk=False, norm="slaney") -- the recipe
+// openai-whisper's assets/mel_filters.npz was made with (export_m80.py:4 reads "mel_80").
+void wm_mel_filterbank(int n_mels, std::vector<float> &out) {
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = 1000.0 / f_sp;
+    const double logstep = log(6.4) / 27.0;
+    auto hz_to_mel = [&](double f) {
+        return f >= min_log_hz ? min_log_mel + log(f / min_log_hz) / logstep : f / f_sp;
+    };
+    auto mel_to_hz = [&](double m) {
+        return m >= min_log_mel ? min_log_hz * exp(logstep * (m - min_log_mel)) : f_sp * m;
+    };
+    const int nb = WM_N_BINS;
+    std::vector<double> fft_f(nb), mel_f(n_mels + 2);
+    for (int k = 0; k < nb; ++k) fft_f[k] = 8000.0 * k / (nb - 1);
+    const double m_lo = hz_to_mel(0.0), m_hi = hz_to_mel(8000.0);
+    for (int i = 0; i < n_mels + 2; ++i)
+        mel_f[i] = mel_to_hz(m_lo + (m_hi - m_lo) * i / (n_mels + 1));
+    out.assign((size_t)n_mels * nb, 0.0f);
+    for (int i = 0; i < n_mels; ++i) {
+        const double d0 = mel_f[i + 1] - mel_f[i], d1 = mel_f[i + 2] - mel_f[i + 1];
+        const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+        for (int k = 0; k < nb; ++k) {
+            const double lower = (fft_f[k] - mel_f[i]) / d0;
+            const double upper = (mel_f[i + 2] - fft_f[k]) / d1;
+            double w = lower < upper ? lower : upper;
+            if (w < 0) w = 0;
+            // librosa stores the triangle in an f32 array, then scales it in place
+            const float w32 = (float)w;
+            out[(size_t)i * nb + k] = (float)((double)w32 * enorm);
+        }
+    }
+}
+
+static int build_bands(const float *filt, int n_mels, int **d_start, int **d_len, float **d_w,
+                       hipStream_t s) {
+    std::vector<int> st(n_mels), ln(n_mels);
+    std::vector<float> w((size_t)n_mels * WM_MEL_MAXW, 0.0f);
+    for (int m = 0; m < n_mels; ++m) {
+        int lo = -1, hi = -1;
+        for (int k = 0; k < WM_N_BINS; ++k)
+            if (filt[m * WM_N_BINS + k] != 0.0f) {
+                if (lo < 0) lo = k;
+                hi = k;
+            }
+        if (lo < 0) {
+            lo = 0;
+            hi = -1;
+        }
+        WM_REQUIRE(hi - lo + 1 <= WM_MEL_MAXW, WM_ERR_INVALID, "mel band %d too wide", m);
+        st[m] = lo;
+        ln[m] = hi - lo + 1;
+        for (int k = lo; k <= hi; ++k) w[(size_t)m * WM_MEL_MAXW + (k - lo)] = filt[m * WM_N_BINS + k];
+    }
+    WM_TRY(upload(d_start, st, s));
+    WM_TRY(upload(d_len, ln, s));
+    WM_TRY(upload(d_w, w, s));
+    return WM_OK;
+}
+
+int wm_frontend_init(WmFrontend *fe, hipStream_t stream) {
+    if (fe->ready) return WM_OK;
+    const double PI = 3.14159265358979323846264338327950288;
+    std::vector<double> c64((size_t)200 * TW_COLS, 0.0), s64((size_t)200 * TW_COLS, 0.0), w64(401);
+    // exact argument reduction: angle index (k*n) mod 400, table of 400 f64 values
+    std::vector<double> ct(400), stb(400);
+    for (int t = 0; t < 400; ++t) {
+        ct[t] = cos(2.0 * PI * t / 400.0);
+        stb[t] = sin(2.0 * PI * t / 400.0);
+    }
+    // exact zeros / ones where the angle is a multiple of pi/2
+    ct[100] = 0.0; ct[300] = 0.0; stb[0] = 0.0; stb[200] = 0.0;
+    for (int n = 1; n <= 200; ++n)
+        for (int k = 0; k < WM_N_BINS; ++k) {
+            const int t = (n * k) % 400;
+            c64[(size_t)(n - 1) * TW_COLS + k] = ct[t];
+            s64[(size_t)(n - 1) * TW_COLS + k] = stb[t];
+        }
+    for (int i = 0; i <= 400; ++i) w64[i] = (1.0 - cos(((double)i * 2.0 * PI) / 400.0)) / 2.0;  // lib.rs:26
+    std::vector<float> c32(c64.begin(), c64.end()), s32(s64.begin(), s64.end()),
+        w32(w64.begin(), w64.end());
+    WM_TRY(upload(&fe->cos64, c64, stream));
+    WM_TRY(upload(&fe->sin64, s64, stream));
+    WM_TRY(upload(&fe->win64, w64, stream));
+    WM_TRY(upload(&fe->cos32, c32, stream));
+    WM_TRY(upload(&fe->sin32, s32, stream));
+    WM_TRY(upload(&fe->win32, w32, stream));
+    WM_TRY(build_bands(kMel80, 80, &fe->band_start[0], &fe->band_len[0], &fe->band_w[0], stream));
+    std::vector<float> m128;
+    wm_mel_filterbank(128, m128);
+    WM_TRY(build_bands(m128.data(), 128, &fe->band_start[1], &fe->band_len[1], &fe->band_w[1],
+                       stream));
+    fe->ready = true;
+    return WM_OK;
+}
+
+void wm_frontend_destroy(WmFrontend *fe) {
+    void *ptrs[] = {fe->cos32, fe->sin32, fe->win32, fe->cos64, fe->sin64, fe->win64,
+                    fe->band_start[0], fe->band_start[1], fe->band_len[0], fe->band_len[1],
+                    fe->band_w[0], fe->band_w[1], fe->gmax, fe->scratch};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    *fe = WmFrontend();
+}
+
+int wm_frontend_run(WmFrontend *fe, WmProfiler *prof, hipStream_t stream, const void *d_pcm,
+                    wm_dtype pcm_dtype, int n_chunks, int n_mels, void *d_out,
+                    wm_dtype out_dtype) {
+    WM_REQUIRE(fe->ready, WM_ERR_STATE, "front end not initialised");
+    WM_REQUIRE(n_mels == 80 || n_mels == 128, WM_ERR_INVALID, "n_mels must be 80 or 128, got %d", n_mels);
+    WM_REQUIRE(pcm_dtype == WM_I16 || pcm_dtype == WM_F32 || pcm_dtype == WM_F64, WM_ERR_INVALID,
+               "pcm dtype must be i16/f32/f64");
+    WM_REQUIRE(out_dtype == WM_F32 || out_dtype == WM_F64, WM_ERR_INVALID, "out dtype must be f32/f64");
+    if (n_chunks == 0) return WM_OK;
+    WM_REQUIRE(n_chunks > 0 && d_pcm && d_out, WM_ERR_INVALID, "bad n_chunks / null pointer");
+    const int fi = (n_mels == 80) ? 0 : 1;
+    if (fe->gmax_cap < n_chunks) {
+        if (fe->gmax) WM_HIP(hipFree(fe->gmax));
+        fe->gmax = nullptr;
+        WM_HIP(hipMalloc(&fe->gmax, sizeof(unsigned long long) * n_chunks));
+        fe->gmax_cap = n_chunks;
+    }
+    WM_HIP(hipMemsetAsync(fe->gmax, 0, sizeof(unsigned long long) * n_chunks, stream));
+    const size_t total = (size_t)n_chunks * n_mels * WM_N_FRAMES;
+    const int g2 = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (out_dtype == WM_F32) {
+        constexpr int WPB = 4;
+        const int bpc = (WM_N_FRAMES + 16 * WPB - 1) / (16 * WPB);
+        {
+            WmProfScope ps(prof, "logmel_stage1_f32", stream);
+            logmel_stage1<float, WPB><<<n_chunks * bpc, WPB * 64, 0, stream>>>(
+                d_pcm, (int)pcm_dtype, n_mels, fe->cos32, fe->sin32, fe->win32, fe->band_start[fi],
+                fe->band_len[fi], fe->band_w[fi], (float *)d_out, (unsigned long long *)fe->gmax, bpc);
+        }
+        {
+            WmProfScope ps(prof, "logmel_stage2_f32", stream);
+            logmel_stage2<float><<<g2, 256, 0, stream>>>((float *)d_out,
+                                                         (const unsigned long long *)fe->gmax,
+                                                         n_mels * WM_N_FRAMES, total);
+        }
+    } else {
+        constexpr int WPB = 2;
+        const int bpc = (WM_N_FRAMES + 16 * WPB - 1) / (16 * WPB);
+        {
+            WmProfScope ps(prof, "logmel_stage1_f64", stream);
+            logmel_stage1<double, WPB><<<n_chunks * bpc, WPB * 64, 0, stream>>>(
+                d_pcm, (int)pcm_dtype, n_mels, fe->cos64, fe->sin64, fe->win64, fe->band_start[fi],
+                fe->band_len[fi], fe->band_w[fi], (double *)d_out, (unsigned long long *)fe->gmax, bpc);
+        }
+        {
+            WmProfScope ps(prof, "logmel_stage2_f64", stream);
+            logmel_stage2<double><<<g2, 256, 0, stream>>>((double *)d_out,
+                                                          (const unsigned long long *)fe->gmax,
+                                                          n_mels * WM_N_FRAMES, total);
+        }
+    }
+    WM_HIP(hipGetLastError());
+    return WM_OK;
+}

@@ -1,0 +1,121 @@
+// wm_internal.h -- private declarations shared by the translation units of
+// libwhisper_mi355x.so (gfx950 only; nothing here is part of the public C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/whisper_mi355x.h"
+
+// ---------------------------------------------------------------- error plumbing -----
+void wm_set_error(const char *fmt, ...);
+
+#define WM_HIP(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            wm_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,               \
+                         hipGetErrorString(_e));                                          \
+            return WM_ERR_HIP;                                                            \
+        }                                                                                 \
+    } while (0)
+
+#define WM_TRY(expr)                                                                      \
+    do {                                                                                  \
+        int _s = (expr);                                                                  \
+        if (_s != WM_OK) return _s;                                                       \
+    } while (0)
+
+#define WM_REQUIRE(cond, code, ...)                                                       \
+    do {                                                                                  \
+        if (!(cond)) {                                                                    \
+            wm_set_error(__VA_ARGS__);                                                    \
+            return (code);                                                                \
+        }                                                                                 \
+    } while (0)
+
+// ---------------------------------------------------------------- fixed geometry -----
+// Literals of the reference front end (stft/src/lib.rs:24,26,35-37,50-52,112,116).
+constexpr int WM_N_SAMPLES = 480000;  // 16000 * 30
+constexpr int WM_N_FFT = 400;
+constexpr int WM_HOP = 160;
+constexpr int WM_N_BINS = 201;
+constexpr int WM_N_FRAMES = 3000;
+constexpr int WM_MEL_MAXW = 32;  // widest supported filter band (80 mels: 14)
+
+typedef unsigned short bf16_t;  // raw bf16 bits in HBM
+
+// ---------------------------------------------------------------- profiling ----------
+struct WmProfFamily {
+    double ms = 0.0;
+    long n = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct WmProfiler {
+    bool on = false;
+    std::map<std::string, WmProfFamily> fam;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get();
+    void begin(const char *name, hipStream_t s, hipEvent_t *e0);
+    void end(const char *name, hipStream_t s, hipEvent_t e0);
+    void drain();
+    void reset();
+    ~WmProfiler();
+};
+
+struct WmProfScope {
+    WmProfiler *p;
+    const char *name;
+    hipStream_t s;
+    hipEvent_t e0 = nullptr;
+    WmProfScope(WmProfiler *p_, const char *n, hipStream_t s_) : p(p_), name(n), s(s_) {
+        if (p && p->on) p->begin(name, s, &e0);
+    }
+    ~WmProfScope() {
+        if (p && p->on && e0) p->end(name, s, e0);
+    }
+};
+
+// ---------------------------------------------------------------- front end ----------
+struct WmFrontend {
+    // DFT-as-MFMA tables: rows n = 1..200, 208 columns (bins 0..200, rest zero).
+    float *cos32 = nullptr, *sin32 = nullptr, *win32 = nullptr;
+    double *cos64 = nullptr, *sin64 = nullptr, *win64 = nullptr;
+    // banded mel filters per supported n_mels (index 0: 80, index 1: 128)
+    int *band_start[2] = {nullptr, nullptr};
+    int *band_len[2] = {nullptr, nullptr};
+    float *band_w[2] = {nullptr, nullptr};  // [n_mels][WM_MEL_MAXW]
+    void *gmax = nullptr;                   // per-chunk encoded maxima (u64 per chunk)
+    int gmax_cap = 0;
+    void *scratch = nullptr;                // staging for host-pointer calls
+    size_t scratch_bytes = 0;
+    bool ready = false;
+};
+
+int wm_frontend_init(WmFrontend *fe, hipStream_t stream);
+void wm_frontend_destroy(WmFrontend *fe);
+// Device-pointer core: pcm [n][480000] (dtype) -> out [n][n_mels][3000] (f32 or f64).
+int wm_frontend_run(WmFrontend *fe, WmProfiler *prof, hipStream_t stream, const void *d_pcm,
+                    wm_dtype pcm_dtype, int n_chunks, int n_mels, void *d_out,
+                    wm_dtype out_dtype);
+// Host-side slaney mel filterbank generator (librosa.filters.mel semantics; used for
+// n_mels = 128 and validated against the reference's m80.npy at n_mels = 80).
+void wm_mel_filterbank(int n_mels, std::vector<float> &out /* [n_mels][201] */);
+const float *wm_mel80_table();
+
+// ---------------------------------------------------------------- context ------------
+struct WmModel;  // model.h
+
+struct wm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    WmProfiler prof;
+    WmFrontend fe;
+    WmModel *model = nullptr;
+    float stage_ms[3] = {0, 0, 0};
+};
+
+int wm_ctx_make_current(const wm_ctx *ctx);

@@ -1,0 +1,75 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads here (hipcc cross-compiled,
+no GPU), exports every symbol include/*.h declares, reports errors without aborting, and
+its host-side pieces (mel filterbank generator) match the reference artefact."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+from conftest import ROOT
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text)
+    return sorted({n for n in names if n.startswith(("wm_", "wmdbg_")) or n == "generate_spectrogram"})
+
+
+def test_every_declared_symbol_is_exported(pkg):
+    lib = pkg.load_library()
+    for hdr in ("whisper_mi355x.h", "whisper_mi355x_debug.h"):
+        names = _declared(hdr)
+        assert names, hdr
+        for n in names:
+            assert hasattr(lib, n), "%s declared in %s but not exported" % (n, hdr)
+    assert "generate_spectrogram" in _declared("whisper_mi355x.h")  # bridge.h:11
+
+
+def test_library_does_not_link_the_oracle(pkg):
+    import subprocess
+    out = subprocess.run(["readelf", "-d", pkg.binding.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    syms = subprocess.run(["nm", "-D", pkg.binding.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle_" not in syms
+
+
+def test_no_device_is_an_error_not_a_fallback(pkg):
+    """In the build container there is no GPU: creation must fail with WM_ERR_HIP."""
+    import torch  # noqa: F401  (only to learn whether a GPU exists)
+    if torch.cuda.is_available():
+        return
+    lib = pkg.load_library()
+    h = ctypes.c_void_p()
+    st = lib.wm_create_frontend(0, ctypes.byref(h))
+    assert st == 2 and not h  # WM_ERR_HIP
+    assert lib.wm_last_error()
+
+
+def test_mel_generator_reproduces_reference_artefact(pkg, m80):
+    # KAT-6: slaney generator at n_mels = 80 vs stft/src/m80.npy (gate 2e-9; measured: bit-exact)
+    lib = pkg.load_library()
+    out = np.zeros((80, 201), dtype=np.float32)
+    assert lib.wmdbg_mel_filterbank(80, out.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert np.abs(out - m80).max() <= 2e-9
+    emb = np.zeros((80, 201), dtype=np.float32)
+    assert lib.wmdbg_mel80(emb.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert np.array_equal(emb, m80)
+
+
+def test_mel128_matches_independent_generator(pkg):
+    from transformers.audio_utils import mel_filter_bank
+    lib = pkg.load_library()
+    out = np.zeros((128, 201), dtype=np.float32)
+    assert lib.wmdbg_mel_filterbank(128, out.ctypes.data_as(ctypes.c_void_p)) == 0
+    t = mel_filter_bank(201, 128, 0, 8000, 16000, norm="slaney", mel_scale="slaney").T
+    assert np.abs(out - t).max() <= 1e-8
+    assert not out[:, 0].any() and (out >= 0).all()
+
+
+def test_bad_arguments_are_reported(pkg):
+    lib = pkg.load_library()
+    assert lib.wm_logmel(None, None, 1, 1, 80, None, 1, 0) != 0
+    assert b"null" in lib.wm_last_error()
+    assert lib.wmdbg_mel_filterbank(0, None) != 0

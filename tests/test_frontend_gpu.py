@@ -1,0 +1,161 @@
+"""GPU parity tests for boundary #1 (the log-mel front end), through the C ABI.
+
+Gates (BASELINE.md / SURVEY.md 8c):  framing + index map bit-exact;  f64 ABI-exact path
+<= 1e-9 abs vs the f64 oracle;  f32 fast path <= 1e-4 abs vs the f64 oracle."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, oracle_logmel
+from oracle import logmel_np as L
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(GOLDEN, "logmel_golden.npz"))
+TOL64 = 1e-9
+TOL32 = 1e-4
+
+
+@pytest.fixture(scope="module")
+def fe(pkg):
+    ctx = pkg.binding.Context()
+    yield ctx
+    ctx.close()
+
+
+def _case(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(GOLDEN, "make_golden.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    if name == "cos3":
+        return mk.structured_chunk()
+    if name == "quiet_tail":
+        q = L.synth_chunk(2).copy()
+        q[160000:] = 0
+        return q
+    return L.synth_chunk(int(name[-1]))
+
+
+def test_generate_spectrogram_symbol_vs_oracle(pkg, oracle_lib):
+    """The reference's own symbol + calling convention (stft.swift:8-19)."""
+    x = L.synth_chunk(0).astype(np.float64)
+    want, want_buf = oracle_logmel(oracle_lib, x)
+    lib = pkg.load_library()
+    buf = np.zeros(480400)
+    buf[200:480200] = x
+    out = np.full(240000, np.nan)
+    lib.generate_spectrogram(buf.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(buf, want_buf), "in-place reflect pad (lib.rs:34-40) must be bit-exact"
+    assert np.abs(out.reshape(80, 3000) - want).max() <= TOL64
+    got = pkg.generateSpectrogram(x)
+    assert np.array_equal(got, out)
+
+
+@pytest.mark.parametrize("case", ["noise0", "noise1", "cos3", "quiet_tail"])
+def test_golden_vectors_f64_and_f32(fe, case):
+    x = _case(case)
+    y64 = fe.logmel(x.astype(np.float64), out_dtype=np.float64)[0]
+    assert np.abs(y64[:, GOLD["frames"]] - GOLD[case + "_cols"]).max() <= TOL64
+    s = GOLD[case + "_sum"]
+    assert abs(y64.sum() - s[0]) <= 1e-4 and abs(y64.max() - s[3]) <= TOL64 and abs(y64.min() - s[4]) <= TOL64
+    y32 = fe.logmel(x, out_dtype=np.float32)[0]
+    assert np.abs(y32[:, GOLD["frames"]] - GOLD[case + "_cols"]).max() <= TOL32
+    assert np.abs(y32.astype(np.float64) - y64).max() <= TOL32
+
+
+def test_kats_on_device(fe, m80):
+    z = fe.logmel(np.zeros((1, 480000), np.float32), out_dtype=np.float64)[0]
+    assert np.abs(z + 1.5).max() <= TOL64                       # KAT-1
+    z32 = fe.logmel(np.zeros((1, 480000), np.float32), out_dtype=np.float32)[0]
+    assert np.abs(z32 + 1.5).max() <= TOL32
+    d = fe.logmel(np.ones((1, 480000), np.float64), out_dtype=np.float64)[0]
+    assert np.abs(d[0] - 1.5988866134681166).max() <= TOL64     # KAT-2, every frame incl. edges
+    assert np.abs(d[1] - 1.3247581029878088).max() <= TOL64
+    assert np.abs(d[2:] + 0.40111338653188344).max() <= TOL64
+
+
+def test_frame_index_map_bit_exact(fe, oracle_lib):
+    """KAT-4: a single impulse lights exactly the frames whose window covers it, and
+    impulses inside the reflected margins light the mirrored frames too."""
+    for pos in (0, 1, 199, 200, 5000, 479999, 479800):
+        x = np.zeros(480000, np.float64)
+        x[pos] = 1.0
+        got = fe.logmel(x, out_dtype=np.float64)[0]
+        want, _ = oracle_logmel(oracle_lib, x)
+        floor_g, floor_w = got.min(), want.min()
+        assert np.array_equal(got > floor_g + 1e-6, want > floor_w + 1e-6), pos
+        assert np.abs(got - want).max() <= TOL64
+
+
+def test_int16_input_convention(fe, oracle_lib):
+    x = L.synth_chunk(4)
+    s = np.round(x * 32767).astype(np.int16)
+    want, _ = oracle_logmel(oracle_lib, s.astype(np.float64) / 32768.0)
+    got64 = fe.logmel(s, out_dtype=np.float64)[0]
+    assert np.abs(got64 - want).max() <= TOL64
+    got32 = fe.logmel(s, out_dtype=np.float32)[0]
+    assert np.abs(got32 - want).max() <= TOL32
+
+
+def test_batch_max_is_per_chunk(fe, oracle_lib):
+    """lib.rs:82-88: the clamp floor is per CHUNK, never per batch."""
+    xs = np.stack([L.synth_chunk(0), 1e-3 * L.synth_chunk(1), np.zeros(480000, np.float32),
+                   L.synth_chunk(2), 30.0 * L.synth_chunk(3)])
+    got = fe.logmel(xs, out_dtype=np.float32)
+    got64 = fe.logmel(xs.astype(np.float64), out_dtype=np.float64)
+    for i in range(len(xs)):
+        want, _ = oracle_logmel(oracle_lib, xs[i])
+        assert np.abs(got[i] - want).max() <= TOL32, i
+        assert np.abs(got64[i] - want).max() <= TOL64, i
+
+
+def test_mel128_for_large_v3(fe, pkg, oracle_lib):
+    lib = pkg.load_library()
+    f128 = np.zeros((128, 201), np.float32)
+    assert lib.wmdbg_mel_filterbank(128, f128.ctypes.data_as(ctypes.c_void_p)) == 0
+    x = L.synth_chunk(7)
+    want, _ = oracle_logmel(oracle_lib, x, filt=f128)
+    got64 = fe.logmel(x.astype(np.float64), n_mels=128, out_dtype=np.float64)[0]
+    got32 = fe.logmel(x, n_mels=128, out_dtype=np.float32)[0]
+    assert got64.shape == (128, 3000)
+    assert np.abs(got64 - want).max() <= TOL64
+    assert np.abs(got32 - want).max() <= TOL32
+
+
+def test_device_resident_buffers(fe, oracle_lib):
+    xs = np.stack([L.synth_chunk(8), L.synth_chunk(9)])
+    d_in = fe.to_device(xs)
+    d_out = fe.dev_malloc(2 * 80 * 3000 * 4)
+    lib = fe.lib
+    st = lib.wm_logmel(fe.handle, d_in, 1, 2, 80, d_out, 1, 1)
+    assert st == 0, lib.wm_last_error()
+    got = fe.download(d_out, (2, 80, 3000), np.float32)
+    for i in range(2):
+        want, _ = oracle_logmel(oracle_lib, xs[i])
+        assert np.abs(got[i] - want).max() <= TOL32
+    fe.dev_free(d_in)
+    fe.dev_free(d_out)
+
+
+def test_empty_and_invalid(fe):
+    lib = fe.lib
+    assert lib.wm_logmel(fe.handle, None, 1, 0, 80, None, 1, 0) == 0       # empty batch is a no-op
+    x = np.zeros((1, 480000), np.float32)
+    o = np.zeros((1, 80, 3000), np.float32)
+    p, q = x.ctypes.data_as(ctypes.c_void_p), o.ctypes.data_as(ctypes.c_void_p)
+    assert lib.wm_logmel(fe.handle, p, 1, 1, 64, q, 1, 0) == 1             # n_mels not 80/128
+    assert lib.wm_logmel(fe.handle, p, 3, 1, 80, q, 1, 0) == 1             # bf16 pcm unsupported
+    assert lib.wm_logmel(fe.handle, p, 1, 1, 80, q, 0, 0) == 1             # i16 output unsupported
+    assert lib.wm_logmel(fe.handle, p, 1, -1, 80, q, 1, 0) == 1
+
+
+def test_profiler_reports_kernel_families(fe):
+    fe.profile_reset()
+    fe.profile_enable(True)
+    fe.logmel(np.zeros((2, 480000), np.float32))
+    prof = fe.profile()
+    fe.profile_enable(False)
+    assert prof["logmel_stage1_f32"]["n"] == 1 and prof["logmel_stage1_f32"]["ms"] > 0

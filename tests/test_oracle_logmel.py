@@ -1,0 +1,108 @@
+"""CPU tests: pin the oracle (oracle/logmel_ref.c + oracle/logmel_np.py) to the
+reference's artefact, the analytic known answers derived from stft/src/lib.rs, and the
+committed golden vectors.  No GPU."""
+import ctypes
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, oracle_logmel
+from oracle import logmel_np as L
+
+GOLD = np.load(os.path.join(GOLDEN, "logmel_golden.npz"))
+
+
+def test_m80_fixture_is_the_reference_artefact(m80):
+    # KAT-0: the file embedded at stft/src/lib.rs:9
+    raw = open(os.path.join(GOLDEN, "m80.npy"), "rb").read()
+    assert hashlib.sha256(raw).hexdigest() == \
+        "3cd88ccebda3c0589c05574824909c8fd04fd456c6a5a992fd92652ae6de9580"
+    assert m80.dtype == np.float32 and m80.shape == (80, 201)
+    assert int((m80 != 0).sum()) == 391
+    assert abs(float(m80.sum()) - 1.9990242) < 1e-6 and abs(float(m80.max()) - 0.025880683) < 1e-9
+    assert np.nonzero(m80[0])[0].tolist() == [1] and np.nonzero(m80[1])[0].tolist() == [1, 2]
+    assert not m80[:, 0].any() and not m80[:, 200].any()
+
+
+def test_embedded_filters_equal_fixture(oracle_lib, m80):
+    emb = np.ctypeslib.as_array(oracle_lib.oracle_mel80(), shape=(80 * 201,))
+    assert np.array_equal(emb, m80.ravel())
+
+
+def test_kat_zeros(oracle_lib):
+    # KAT-1: silence => log10(1e-10) = -10 everywhere => (-10+4)/4 = -1.5 exactly
+    y, _ = oracle_logmel(oracle_lib, np.zeros(480000))
+    assert np.all(y == -1.5)
+
+
+def test_kat_dc(oracle_lib):
+    # KAT-2: x == 1 => Hann DC gain 200, bin1 -100 => powers 40000 / 10000
+    y, _ = oracle_logmel(oracle_lib, np.ones(480000))
+    assert np.allclose(y[0], 1.5988866134681166, atol=1e-12)
+    assert np.allclose(y[1], 1.3247581029878088, atol=1e-12)
+    assert np.allclose(y[2:], -0.40111338653188344, atol=1e-12)
+
+
+def test_kat_bin_centred_cosine(oracle_lib, m80):
+    # KAT-3: 1 kHz = bin 25 exactly: power 2500/10000/2500 in bins 24/25/26 of every frame
+    # whose window does not cross the RIGHT reflection point (the cosine is even about n = 0,
+    # so the left margin is seamless, but not about n = 479999: frame 2999 sees a phase jump).
+    n = np.arange(480000)
+    x = np.cos(2 * np.pi * 1000 * n / 16000)
+    y, _ = oracle_logmel(oracle_lib, x)
+    p = np.zeros(201)
+    p[24], p[25], p[26] = 2500.0, 10000.0, 2500.0
+    mel = np.log10(np.maximum(m80.astype(np.float64) @ p, 1e-10))
+    want = (np.maximum(mel, mel.max() - 8.0) + 4.0) / 4.0
+    assert np.allclose(y[:, :2999], want[:, None], atol=1e-9)
+    assert not np.allclose(y[:, 2999], want, atol=1e-3)
+
+
+def test_kat_reflect_and_frame_index(oracle_lib):
+    # KAT-4: lib.rs:34-40 == np.pad(x, 200, "reflect"); 3000 frames; frame j <-> x[160j-200 ...]
+    x = L.synth_chunk(3)
+    _, buf = oracle_logmel(oracle_lib, x)
+    assert np.array_equal(buf, np.pad(x.astype(np.float64), 200, mode="reflect"))
+    idx = L.frame_index()
+    assert idx.shape == (3000, 400) and idx[0, 0] == 0 and idx[-1, -1] == 480239
+    assert np.array_equal(L.reflect_pad(x.astype(np.float64)), buf)
+
+
+@pytest.mark.parametrize("case,seed", [("noise0", 0), ("noise1", 1)])
+def test_c_oracle_vs_numpy_and_golden(oracle_lib, m80, case, seed):
+    x = L.synth_chunk(seed)
+    y, _ = oracle_logmel(oracle_lib, x)
+    assert np.abs(y - L.log_mel(x, m80)).max() <= 1e-12
+    assert np.abs(y[:, GOLD["frames"]] - GOLD[case + "_cols"]).max() <= 1e-12
+    s = GOLD[case + "_sum"]
+    assert abs(y.sum() - s[0]) <= 1e-7 and abs(y.max() - s[3]) <= 1e-12 and abs(y.min() - s[4]) <= 1e-12
+
+
+def test_fft_agrees_with_naive_dft(oracle_lib):
+    x = L.synth_chunk(5)
+    y_fft, _ = oracle_logmel(oracle_lib, x)
+    oracle_lib.oracle_set_naive_dft(1)
+    try:
+        y_dft, _ = oracle_logmel(oracle_lib, x)
+    finally:
+        oracle_lib.oracle_set_naive_dft(0)
+    assert np.abs(y_fft - y_dft).max() <= 1e-12
+
+
+def test_filter_variant_equals_fixed_symbol(oracle_lib, m80):
+    x = L.synth_chunk(6)
+    a, _ = oracle_logmel(oracle_lib, x)
+    b, _ = oracle_logmel(oracle_lib, x, filt=m80)
+    assert np.array_equal(a, b)
+
+
+def test_batch_entry_matches_single(oracle_lib):
+    x = np.stack([L.synth_chunk(0), L.synth_chunk(1)])
+    out = np.zeros((2, 80, 3000))
+    oracle_lib.oracle_logmel_batch_f32(x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(2),
+                                       out.ctypes.data_as(ctypes.c_void_p))
+    for i in range(2):
+        y, _ = oracle_logmel(oracle_lib, x[i])
+        assert np.array_equal(out[i], y)
