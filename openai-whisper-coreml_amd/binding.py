@@ -76,7 +76,7 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise WhisperError(-1, "%s not found: run `python __graft_entry__.py build` "
                                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
-    lib = ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+    lib = ctypes.CDLL(p)  # RTLD_LOCAL: never interpose another library's symbols
     vp, ip, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     pp = ctypes.POINTER(ctypes.c_void_p)
     lib.generate_spectrogram.argtypes = [vp, vp]

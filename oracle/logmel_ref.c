@@ -196,11 +196,15 @@ static void spectrogram(const double *audio, const float *filt, int n_mels, doub
 }
 
 /* ---- the reference's FFI entry (lib.rs:110-122; bridge.h:11) ----------------------- */
-void generate_spectrogram(double *audio, double *output) {
+static void generate_spectrogram_impl(double *audio, double *output) {
     oracle_init();
     reflect(audio);                          /* lib.rs:113 (mutates the caller's buffer) */
     spectrogram(audio, MEL80, 80, output);   /* lib.rs:114-121 */
 }
+/* The exported name is the reference's; internal callers use the static _impl so that a
+ * process which also has the PRODUCT library's generate_spectrogram loaded can never have
+ * one interposed for the other. */
+void generate_spectrogram(double *audio, double *output) { generate_spectrogram_impl(audio, output); }
 
 /* Same pipeline with a caller-supplied filterbank (128 mels for large-v3). */
 void oracle_generate_spectrogram_filt(double *audio, double *output, const float *filt,
@@ -219,7 +223,7 @@ void oracle_logmel_batch_f32(const float *pcm, int n_chunks, double *out) {
     for (int c = 0; c < n_chunks; ++c) {
         memset(buf, 0, sizeof(double) * N_PADDED);
         for (int i = 0; i < N_SAMPLES; ++i) buf[200 + i] = (double)pcm[(size_t)c * N_SAMPLES + i];
-        generate_spectrogram(buf, out + (size_t)c * 80 * N_FRAMES);
+        generate_spectrogram_impl(buf, out + (size_t)c * 80 * N_FRAMES);
     }
     free(buf);
 }
