@@ -21,6 +21,25 @@ int wmdbg_mel_filterbank(int n_mels, float *out);
 /* Host-only: the embedded copy of the reference's m80.npy (80*201 f32). */
 int wmdbg_mel80(float *out);
 
+/* ---- single-kernel hooks (GPU).  Matrices are given as f32 and rounded to bf16 inside,
+ * exactly as the weights / activations are held in HBM. ---------------------------------- */
+/* C[M][N] = A[M][K] . W[N][K]^T (+bias); epi: 6 = f32 out, 0 = bf16 out, 1 = gelu -> bf16,
+ * 2 = C += (f32 residual).  K % 64 == 0.  C is f32 on the host in every case. */
+int wmdbg_gemm(wm_ctx *ctx, const float *A, const float *W, const float *bias, float *C, int M, int N,
+               int K, int epi);
+/* LayerNorm over the last axis (eps 1e-5): f32 result and the bf16 result widened to f32. */
+int wmdbg_layernorm(wm_ctx *ctx, const float *x, const float *g, const float *b, int rows, int d,
+                    float *out_f32, float *out_bf16_as_f32);
+/* Non-causal MHA, head_dim 64: q,k,v,out f32 [B][S][H*64]. */
+int wmdbg_enc_attention(wm_ctx *ctx, const float *q, const float *k, const float *v, int B, int H, int S,
+                        float *out);
+/* Decode-step skinny GEMM: out[B][N] = (ln_g ? LayerNorm(x) : x) . W[N][K]^T + bias; B <= 16. */
+int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, const float *ln_b, const float *W,
+                   const float *bias, float *out, int B, int N, int K);
+/* Single-query attention over a cache: q [B][H*64], k/v [B][H][T][64], keys 0..n_keys-1. */
+int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, const float *v, int B, int H, int T,
+                        int n_keys, int nsplit, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,7 +1,192 @@
 // model.h -- Whisper encoder/decoder state (weights, activations, KV caches) and the
-// launch wrappers of the HIP kernels that implement boundary #2.
+// launch wrappers of the HIP kernels that implement boundary #2
+// (Whisper/Whisper/Whisper.swift:17-40; graph contract whisper_to_cml.py:10-43; arithmetic
+// = openai-whisper AudioEncoder / TextDecoder).
 #pragma once
 #include "wm_internal.h"
 
+// ---------------------------------------------------------------- HBM layout ----------
+// All matrix weights are bf16 [N][K] row-major (PyTorch Linear layout: K contiguous), so
+// both MFMA operands are K-contiguous.  Vectors (biases, LayerNorm, positions) are f32.
+struct EncLayerW {
+    float *ln1_g, *ln1_b;
+    bf16_t *wqkv;  // [3d][d]  rows: query | key | value
+    float *bqkv;   // [3d]     (key bias = 0: openai-whisper's key Linear has no bias)
+    bf16_t *wo;    // [d][d]
+    float *bo;
+    float *ln2_g, *ln2_b;
+    bf16_t *w1;  // [4d][d]
+    float *b1;
+    bf16_t *w2;  // [d][4d]
+    float *b2;
+};
+struct DecLayerW {
+    float *ln1_g, *ln1_b;
+    bf16_t *wqkv;  // [3d][d]
+    float *bqkv;
+    bf16_t *wo;
+    float *bo;
+    float *lnx_g, *lnx_b;  // cross_attn_ln
+    bf16_t *wxq;           // [d][d]
+    float *bxq;
+    bf16_t *wxkv;  // [2d][d]  rows: key | value   (applied to the encoder output)
+    float *bxkv;   // [2d]     (key half = 0)
+    bf16_t *wxo;
+    float *bxo;
+    float *ln2_g, *ln2_b;
+    bf16_t *w1;
+    float *b1;
+    bf16_t *w2;
+    float *b2;
+};
+
+// One registry entry per openai-whisper state-dict key: where its elements live in HBM.
+enum WmLayout { WL_PLAIN = 0, WL_CONV = 1 };  // WL_CONV: [O][C][3] -> [O][Kpad], k = tap*C + c
+struct WmTensor {
+    std::string name;
+    void *ptr = nullptr;  // destination of logical element 0
+    bool is_bf16 = false;
+    size_t n_elems = 0;
+    int layout = WL_PLAIN;
+    int conv_c = 0, conv_kpad = 0;
+    int kind = 0;  // K_MATRIX..K_SINUSOID of weights.py (synthetic generator)
+    bool set = false;
+};
+
+struct WmModel {
+    wm_dims dims;
+    bool finalized = false;
+    int k1pad = 0;  // conv1 GEMM K (3*n_mels rounded up to 64)
+    int vpad = 0;   // n_vocab rounded up to 16 (token embedding rows)
+    // weights
+    bf16_t *conv1_w = nullptr, *conv2_w = nullptr;
+    float *conv1_b = nullptr, *conv2_b = nullptr, *enc_pos = nullptr;
+    std::vector<EncLayerW> enc;
+    float *ln_post_g = nullptr, *ln_post_b = nullptr;
+    bf16_t *tok_emb = nullptr;  // [vpad][d]
+    float *dec_pos = nullptr;   // [n_text_ctx][d]
+    std::vector<DecLayerW> dec;
+    float *ln_g = nullptr, *ln_b = nullptr;
+    std::vector<void *> allocs;
+    std::vector<WmTensor> tensors;
+    std::map<std::string, int> index;
+    // activations (sized for `cap_b` chunks)
+    int cap_b = 0;
+    bf16_t *mel_t = nullptr;  // [B][3002][n_mels]  time-major, zero rows 0 and 3001
+    bf16_t *h1p = nullptr;    // [B][3001][d]       conv1 output, zero row 0
+    float *x = nullptr;       // [B*1500][d]        encoder residual stream (f32)
+    bf16_t *xn = nullptr;     // [B*1500][d]        LayerNorm output / encoder output (bf16)
+    bf16_t *qk = nullptr;     // [B*1500 + 64][2d]  q | k
+    bf16_t *vt = nullptr;     // [B][H][64][1536]   v transposed (s contiguous)
+    bf16_t *att = nullptr;    // [B*1500][d]
+    bf16_t *hid = nullptr;    // [B*1500][4d]
+    float *xa_f32 = nullptr;  // [B*1500][d]        ln_post output (API output)
+    float *mel_f32 = nullptr; // [B][n_mels][3000]  front-end output kept on device
+    bf16_t *xkv = nullptr;    // [L][2][B][H][1500][64]  cross-attention K/V cache
+    bf16_t *skv = nullptr;    // [L][2][B][H][n_text_ctx][64] self-attention K/V cache
+    // decode-step buffers
+    float *dx = nullptr;        // [16][d]   decoder residual stream
+    float *dq = nullptr;        // [16][d]   query (self or cross)
+    float *dpart = nullptr;     // [B][H][NSPLIT_MAX][66] attention partials (m, l, o[64])
+    bf16_t *dhid = nullptr;     // [16][4d]
+    float *dlogits = nullptr;   // [B][vpad]
+    unsigned long long *dargmax = nullptr;  // [16][vpad/16] per-tile packed (value, ~index) maxima
+    int *dresult = nullptr;     // [16] arg-max result relative to arg_first
+    int *dtokens = nullptr;     // [B][n_text_ctx] token history on device
+    int *dcur = nullptr;        // [B] current input token
+    void *pcm_stage = nullptr;  // host-pointer staging for wm_transcribe_greedy
+    size_t pcm_stage_bytes = 0;
+    float *io_stage = nullptr;  // staging for host-pointer model calls
+    size_t io_stage_bytes = 0;
+};
+
+// model.cpp
 int wm_model_create(wm_ctx *ctx, const wm_dims *dims);
 void wm_model_destroy(wm_ctx *ctx);
+int wm_model_reserve(wm_ctx *ctx, int B);
+int wm_model_set_tensor(wm_ctx *ctx, const char *name, const float *data, size_t n);
+int wm_model_get_tensor(wm_ctx *ctx, const char *name, float *data, size_t n);
+int wm_model_init_synthetic(wm_ctx *ctx, uint64_t seed);
+int wm_model_finalize(wm_ctx *ctx);
+// device-pointer cores
+int wm_model_encode_dev(wm_ctx *ctx, const float *d_mel, int B, float *d_xa_out /*nullable*/);
+int wm_model_cross_kv(wm_ctx *ctx, int B);                 // from m->xn (bf16 encoder output)
+int wm_model_set_xa(wm_ctx *ctx, const float *d_xa, int B);  // f32 xa -> m->xn (bf16)
+int wm_model_decode_begin(wm_ctx *ctx, int B);
+// One decoder position for all B sequences: input tokens d_tokens[0..B) at position `pos`.
+// want_logits: f32 logits [B][vpad] -> m->dlogits;  want_argmax / want_logits: per-tile
+// packed maxima over [arg_first, arg_last] -> m->dargmax (reduce with wm_argmax_reduce).
+int wm_model_decode_step(wm_ctx *ctx, int B, int pos, const int *d_tokens, bool want_logits, bool want_argmax,
+                         int arg_first, int arg_last);
+
+// ---------------------------------------------------------------- kernel launchers ----
+// gemm.hip
+enum GemmEpi {
+    EPI_BIAS_BF16 = 0,  // C bf16 [.][ldc] = acc + bias
+    EPI_GELU_BF16 = 1,  // C bf16 = gelu(acc + bias)
+    EPI_RESID_F32 = 2,  // C f32 += acc + bias
+    EPI_CONV2_F32 = 3,  // C f32 = gelu(acc + bias) + pos[m % rows_per_batch][n]
+    EPI_QKV_ENC = 4,    // n < 2d: C bf16 [m][2d];  n >= 2d: vt[b][h][e][s]
+    EPI_XKV = 5,        // cross K/V cache scatter
+    EPI_F32 = 6         // C f32 = acc + bias (debug / generic)
+};
+struct GemmArgs {
+    const bf16_t *A;   // rows addressed as (m / a_rpb) * a_bstride + (m % a_rpb) * a_rstride
+    long a_rpb, a_bstride, a_rstride;
+    const bf16_t *W;   // [N][K]
+    const float *bias; // [N] or null
+    void *C;
+    long c_rpb, c_bstride, c_rstride;  // same row addressing for C (elements)
+    int M, N, K;
+    int epi;
+    // epilogue extras
+    const float *pos;  // EPI_CONV2_F32
+    bf16_t *vt;        // EPI_QKV_ENC
+    int d_model, n_head, seq, seq_pad, batch;  // EPI_QKV_ENC / EPI_XKV
+};
+int wm_gemm(wm_ctx *ctx, const GemmArgs &g);
+
+// enc_kernels.hip
+int wm_layernorm(wm_ctx *ctx, const float *x, const float *g, const float *b, int rows, int d,
+                 bf16_t *out_bf16 /*nullable*/, float *out_f32 /*nullable*/);
+int wm_mel_to_time_major(wm_ctx *ctx, const float *mel, int B, int n_mels, bf16_t *mel_t);
+int wm_f32_to_bf16(wm_ctx *ctx, const float *in, bf16_t *out, size_t n);
+int wm_enc_attention(wm_ctx *ctx, const bf16_t *qk, const bf16_t *vt, bf16_t *att, int B, int H,
+                     int S, int S_pad, int d);
+
+// dec_kernels.hip
+constexpr int WM_DEC_MAXB = 16;
+constexpr int WM_XSPLIT = 4;  // flash-decoding splits of the 1500-frame cross attention
+enum DecAMode { DA_LN = 0, DA_BF16 = 1, DA_ATTN = 2 };
+enum DecEpi { DE_QKV = 0, DE_Q = 1, DE_RESID = 2, DE_GELU = 3, DE_LOGITS = 4 };
+struct DecGemvArgs {
+    int a_mode, epi;
+    int B, N, K;
+    const bf16_t *W;    // [N (padded to 16)][K]
+    const float *bias;  // [N] or null
+    // A operand
+    const float *x;        // DA_LN: residual stream [B][K]
+    const float *ln_g, *ln_b;
+    const bf16_t *a_bf16;  // DA_BF16: [B][K]
+    const float *part;     // DA_ATTN: partials [B][H][nsplit][66]
+    int nsplit;
+    // outputs
+    float *out_f32;        // DE_Q: [B][N]; DE_RESID: residual [B][N] (+=); DE_LOGITS: [B][ldo]
+    bf16_t *out_bf16;      // DE_GELU: [B][N]
+    bf16_t *kcache, *vcache;  // DE_QKV: this layer's [B][H][T][64]
+    int pos, n_ctx, n_head;
+    long ldo;
+    unsigned long long *argmax;  // DE_LOGITS: per-tile packed maxima [B][ceil(N/16)] over [arg_first, arg_last]
+    int arg_first, arg_last;
+};
+int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a);
+int wm_dec_embed(wm_ctx *ctx, const int *tokens, int B, int pos, const bf16_t *emb, const float *pemb,
+                 int d, float *x, unsigned long long *argmax_to_clear);
+// Single-query attention over a K/V cache [B][H][T][64]; writes partials (m, l, o[64]).
+int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
+                     int T_stride, int n_keys, int nsplit, float *part);
+// Reduce the per-tile packed maxima of a DE_LOGITS launch: next token -> cur[b] / history,
+// and (token - arg_first) -> result[b] (any of the three may be null).
+int wm_argmax_reduce(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *cur,
+                     int *history, int hist_stride, int hist_pos, int *result, int arg_first);
+int wm_fill_synthetic(wm_ctx *ctx, const WmTensor &t, uint32_t seed, int tensor_id);

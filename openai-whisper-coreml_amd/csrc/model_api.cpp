@@ -1,17 +1,483 @@
-// model_api.cpp -- boundary #2 entry points (placeholder until the model lands).
+// model_api.cpp -- boundary #2 of the C ABI (include/whisper_mi355x.h): weight loading, the
+// encoder / decoder entry points that replace the CoreML `encoder` / `decoder` classes
+// (Whisper/Whisper/Whisper.swift:17-40), the KV-cached greedy transcription asked for by
+// BASELINE.json, and the per-kernel test hooks (include/whisper_mi355x_debug.h).
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/whisper_mi355x_debug.h"
 #include "model.h"
-int wm_model_create(wm_ctx *, const wm_dims *) { wm_set_error("model not built yet"); return WM_ERR_STATE; }
-void wm_model_destroy(wm_ctx *) {}
-#define STUB { wm_set_error("model not built yet"); return WM_ERR_STATE; }
-extern "C" {
-int wm_set_tensor(wm_ctx *, const char *, const float *, size_t) STUB
-int wm_get_tensor(wm_ctx *, const char *, float *, size_t) STUB
-int wm_load_weights(wm_ctx *, const char *) STUB
-int wm_init_synthetic(wm_ctx *, uint64_t) STUB
-int wm_finalize(wm_ctx *) STUB
-int wm_get_dims(const wm_ctx *, wm_dims *) STUB
-int wm_encode(wm_ctx *, const float *, int, float *, wm_mem) STUB
-int wm_decode_logits(wm_ctx *, const int32_t *, int, int, const float *, float *, wm_mem) STUB
-int wm_detect_language(wm_ctx *, const float *, int, int32_t, int32_t, int32_t, int32_t *, wm_mem) STUB
-int wm_transcribe_greedy(wm_ctx *, const void *, wm_dtype, int, const int32_t *, int, int, int32_t, int32_t *, int32_t *, wm_mem) STUB
+
+#define WM_MODEL(ctx)                                                               \
+    WM_TRY(wm_ctx_make_current(ctx));                                               \
+    WmModel *m = (ctx)->model;                                                      \
+    WM_REQUIRE(m != nullptr, WM_ERR_STATE, "context was created without a model (use wm_create)")
+
+static int io_stage(wm_ctx *ctx, size_t bytes, char **out) {
+    WmModel *m = ctx->model;
+    if (m->io_stage_bytes < bytes) {
+        WM_HIP(hipStreamSynchronize(ctx->stream));
+        if (m->io_stage) WM_HIP(hipFree(m->io_stage));
+        m->io_stage = nullptr;
+        m->io_stage_bytes = 0;
+        WM_HIP(hipMalloc((void **)&m->io_stage, bytes));
+        m->io_stage_bytes = bytes;
+    }
+    *out = (char *)m->io_stage;
+    return WM_OK;
+}
+
+extern "C" int wm_set_tensor(wm_ctx *ctx, const char *name, const float *data, size_t n) {
+    WM_MODEL(ctx);
+    (void)m;
+    return wm_model_set_tensor(ctx, name, data, n);
+}
+extern "C" int wm_get_tensor(wm_ctx *ctx, const char *name, float *data, size_t n) {
+    WM_MODEL(ctx);
+    (void)m;
+    return wm_model_get_tensor(ctx, name, data, n);
+}
+extern "C" int wm_init_synthetic(wm_ctx *ctx, uint64_t seed) {
+    WM_MODEL(ctx);
+    (void)m;
+    return wm_model_init_synthetic(ctx, seed);
+}
+extern "C" int wm_finalize(wm_ctx *ctx) {
+    WM_MODEL(ctx);
+    (void)m;
+    return wm_model_finalize(ctx);
+}
+extern "C" int wm_get_dims(const wm_ctx *ctx, wm_dims *out) {
+    WM_REQUIRE(ctx && out, WM_ERR_INVALID, "null pointer");
+    WM_REQUIRE(ctx->model, WM_ERR_STATE, "context has no model");
+    *out = ctx->model->dims;
+    return WM_OK;
+}
+
+// Flat weight file (format: openai-whisper-coreml_amd/weights.py / DESIGN.md).
+extern "C" int wm_load_weights(wm_ctx *ctx, const char *path) {
+    WM_MODEL(ctx);
+    WM_REQUIRE(path, WM_ERR_INVALID, "null path");
+    FILE *f = fopen(path, "rb");
+    WM_REQUIRE(f, WM_ERR_IO, "cannot open '%s'", path);
+    int st = WM_OK;
+    char magic[8];
+    int32_t dims[10], count = 0;
+    std::vector<float> buf;
+    std::vector<char> name;
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "WMI355X1", 8) != 0 || fread(dims, 4, 10, f) != 10 ||
+        fread(&count, 4, 1, f) != 1) {
+        wm_set_error("'%s' is not a WMI355X1 weight file", path);
+        st = WM_ERR_IO;
+    }
+    if (st == WM_OK && memcmp(dims, &m->dims, sizeof(wm_dims)) != 0) {
+        wm_set_error("'%s': model dimensions differ from the context's", path);
+        st = WM_ERR_IO;
+    }
+    for (int i = 0; st == WM_OK && i < count; ++i) {
+        int32_t nl = 0;
+        int64_t ne = 0;
+        if (fread(&nl, 4, 1, f) != 1 || nl <= 0 || nl > 4096) { wm_set_error("'%s': truncated", path); st = WM_ERR_IO; break; }
+        name.assign(nl + 1, 0);
+        if (fread(name.data(), 1, nl, f) != (size_t)nl || fread(&ne, 8, 1, f) != 1 || ne <= 0) {
+            wm_set_error("'%s': truncated", path); st = WM_ERR_IO; break;
+        }
+        buf.resize((size_t)ne);
+        if (fread(buf.data(), 4, (size_t)ne, f) != (size_t)ne) { wm_set_error("'%s': truncated", path); st = WM_ERR_IO; break; }
+        st = wm_model_set_tensor(ctx, name.data(), buf.data(), (size_t)ne);
+    }
+    fclose(f);
+    return st;
+}
+
+// ------------------------------------------------------------------ encoder ------------
+extern "C" int wm_encode(wm_ctx *ctx, const float *mel, int B, float *xa, wm_mem mem) {
+    WM_MODEL(ctx);
+    WM_REQUIRE(mel && xa && B >= 1, WM_ERR_INVALID, "null pointer / B < 1");
+    if (mem == WM_MEM_DEVICE) return wm_model_encode_dev(ctx, mel, B, xa);
+    const size_t in_b = (size_t)B * m->dims.n_mels * WM_N_FRAMES * 4;
+    const size_t out_b = (size_t)B * 1500 * m->dims.n_audio_state * 4;
+    char *st;
+    WM_TRY(io_stage(ctx, in_b + out_b, &st));
+    WM_HIP(hipMemcpyAsync(st, mel, in_b, hipMemcpyHostToDevice, ctx->stream));
+    WM_TRY(wm_model_encode_dev(ctx, (const float *)st, B, (float *)(st + in_b)));
+    WM_HIP(hipMemcpyAsync(xa, st + in_b, out_b, hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    return WM_OK;
+}
+
+// ------------------------------------------------------------------ decoder ------------
+// Shared: bring xa (f32 [B][1500][d], host or device) into the bf16 encoder-output buffer
+// and build the cross-attention K/V cache.
+static int load_xa(wm_ctx *ctx, const float *xa, int B, wm_mem mem) {
+    WmModel *m = ctx->model;
+    const size_t bytes = (size_t)B * 1500 * m->dims.n_audio_state * 4;
+    const float *d_xa = xa;
+    if (mem == WM_MEM_HOST) {
+        char *st;
+        WM_TRY(io_stage(ctx, bytes, &st));
+        WM_HIP(hipMemcpyAsync(st, xa, bytes, hipMemcpyHostToDevice, ctx->stream));
+        d_xa = (const float *)st;
+    }
+    WM_TRY(wm_model_set_xa(ctx, d_xa, B));
+    return wm_model_cross_kv(ctx, B);
+}
+
+extern "C" int wm_decode_logits(wm_ctx *ctx, const int32_t *tokens, int B, int T, const float *xa,
+                                float *logits, wm_mem mem) {
+    WM_MODEL(ctx);
+    WM_REQUIRE(tokens && xa && logits, WM_ERR_INVALID, "null pointer");
+    WM_REQUIRE(B >= 1 && B <= WM_DEC_MAXB, WM_ERR_INVALID, "B must be 1..%d", WM_DEC_MAXB);
+    WM_REQUIRE(T >= 1 && T <= m->dims.n_text_ctx, WM_ERR_INVALID, "T must be 1..%d", m->dims.n_text_ctx);
+    const int V = m->dims.n_vocab;
+    // tokens arrive [B][T]; the step kernel wants the B tokens of one position contiguous
+    std::vector<int32_t> host_tok((size_t)B * T);
+    if (mem == WM_MEM_DEVICE) {
+        WM_HIP(hipMemcpy(host_tok.data(), tokens, host_tok.size() * 4, hipMemcpyDeviceToHost));
+    } else {
+        memcpy(host_tok.data(), tokens, host_tok.size() * 4);
+    }
+    std::vector<int32_t> tb((size_t)T * B);
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < T; ++t) {
+            const int32_t tok = host_tok[(size_t)b * T + t];
+            WM_REQUIRE(tok >= 0 && tok < V, WM_ERR_INVALID, "token id %d outside [0, %d)", tok, V);
+            tb[(size_t)t * B + b] = tok;
+        }
+    WM_TRY(wm_model_decode_begin(ctx, B));
+    WM_TRY(load_xa(ctx, xa, B, mem));
+    WM_HIP(hipMemcpyAsync(m->dcur, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    float *d_out = logits;
+    char *st = nullptr;
+    if (mem == WM_MEM_HOST) {
+        // io_stage currently holds xa (already consumed into bf16 by load_xa on this stream)
+        WM_HIP(hipMalloc((void **)&st, (size_t)B * T * V * 4));
+        d_out = (float *)st;
+    }
+    int rc = WM_OK;
+    for (int t = 0; t < T && rc == WM_OK; ++t) {
+        rc = wm_model_decode_step(ctx, B, t, m->dcur + (size_t)t * B, true, false, 0, V - 1);
+        if (rc != WM_OK) break;
+        // dlogits [B][vpad] -> out [B][T][V], row t
+        if (hipMemcpy2DAsync(d_out + (size_t)t * V, (size_t)T * V * 4, m->dlogits, (size_t)m->vpad * 4,
+                             (size_t)V * 4, B, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+            wm_set_error("hipMemcpy2DAsync failed");
+            rc = WM_ERR_HIP;
+        }
+    }
+    if (rc == WM_OK && mem == WM_MEM_HOST) {
+        if (hipMemcpyAsync(logits, d_out, (size_t)B * T * V * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
+            wm_set_error("hipMemcpyAsync D2H failed");
+            rc = WM_ERR_HIP;
+        }
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == WM_OK) {
+        wm_set_error("stream sync failed: %s", hipGetErrorString(hipGetLastError()));
+        rc = WM_ERR_HIP;
+    }
+    if (st) (void)hipFree(st);
+    return rc;
+}
+
+extern "C" int wm_detect_language(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first,
+                                  int32_t lang_last, int32_t *lang_idx, wm_mem mem) {
+    WM_MODEL(ctx);
+    WM_REQUIRE(xa && lang_idx, WM_ERR_INVALID, "null pointer");
+    WM_REQUIRE(B >= 1 && B <= WM_DEC_MAXB, WM_ERR_INVALID, "B must be 1..%d", WM_DEC_MAXB);
+    const int V = m->dims.n_vocab;
+    WM_REQUIRE(sot >= 0 && sot < V && lang_first >= 0 && lang_first <= lang_last && lang_last < V, WM_ERR_INVALID,
+               "token ids outside the vocabulary (n_vocab = %d)", V);
+    WM_TRY(wm_model_decode_begin(ctx, B));
+    WM_TRY(load_xa(ctx, xa, B, mem));
+    std::vector<int32_t> sots(B, sot);  // Whisper.swift:34-35
+    WM_HIP(hipMemcpyAsync(m->dcur, sots.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));  // sots is stack-lifetime
+    WM_TRY(wm_model_decode_step(ctx, B, 0, m->dcur, false, true, lang_first, lang_last));  // :36-37
+    WM_TRY(wm_argmax_reduce(ctx, m->dargmax, m->vpad / 16, B, nullptr, nullptr, 0, 0, m->dresult, lang_first));  // :38
+    std::vector<int32_t> res(B);
+    WM_HIP(hipMemcpyAsync(res.data(), m->dresult, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    if (mem == WM_MEM_DEVICE) {
+        WM_HIP(hipMemcpy(lang_idx, res.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+    } else {
+        memcpy(lang_idx, res.data(), (size_t)B * 4);
+    }
+    return WM_OK;
+}
+
+// ------------------------------------------------------------------ greedy transcription
+static size_t pcm_elem(wm_dtype t) { return t == WM_I16 ? 2 : t == WM_F32 ? 4 : 8; }
+
+extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int B,
+                                    const int32_t *prompt, int n_prompt, int max_new, int32_t eot,
+                                    int32_t *tokens_out, int32_t *lens_out, wm_mem mem) {
+    WM_MODEL(ctx);
+    WM_REQUIRE(m->finalized, WM_ERR_STATE, "model weights not finalised (wm_finalize)");
+    WM_REQUIRE(pcm && prompt && tokens_out && lens_out, WM_ERR_INVALID, "null pointer");
+    WM_REQUIRE(pcm_dtype == WM_I16 || pcm_dtype == WM_F32 || pcm_dtype == WM_F64, WM_ERR_INVALID, "bad pcm dtype");
+    WM_REQUIRE(B >= 1, WM_ERR_INVALID, "B < 1");
+    const wm_dims &D = m->dims;
+    WM_REQUIRE(n_prompt >= 1 && max_new >= 1 && n_prompt + max_new <= D.n_text_ctx, WM_ERR_INVALID,
+               "prompt (%d) + new tokens (%d) must fit the %d-token context", n_prompt, max_new, D.n_text_ctx);
+    for (int i = 0; i < n_prompt; ++i)
+        WM_REQUIRE(prompt[i] >= 0 && prompt[i] < D.n_vocab, WM_ERR_INVALID, "prompt token %d out of range", prompt[i]);
+    const size_t chunk_b = (size_t)WM_N_SAMPLES * pcm_elem(pcm_dtype);
+    hipEvent_t ev[4];
+    for (auto &e : ev) WM_HIP(hipEventCreate(&e));
+    ctx->stage_ms[0] = ctx->stage_ms[1] = ctx->stage_ms[2] = 0.f;
+    int rc = WM_OK;
+    // the decoder kernels take <= 16 sequences: larger batches run as consecutive groups
+    for (int b0 = 0; b0 < B && rc == WM_OK; b0 += WM_DEC_MAXB) {
+        const int Bg = (B - b0) < WM_DEC_MAXB ? (B - b0) : WM_DEC_MAXB;
+        const void *d_pcm = (const char *)pcm + (size_t)b0 * chunk_b;
+        if (mem == WM_MEM_HOST) {
+            if (m->pcm_stage_bytes < (size_t)Bg * chunk_b) {
+                WM_HIP(hipStreamSynchronize(ctx->stream));
+                if (m->pcm_stage) WM_HIP(hipFree(m->pcm_stage));
+                m->pcm_stage = nullptr;
+                WM_HIP(hipMalloc(&m->pcm_stage, (size_t)Bg * chunk_b));
+                m->pcm_stage_bytes = (size_t)Bg * chunk_b;
+            }
+            WM_HIP(hipMemcpyAsync(m->pcm_stage, d_pcm, (size_t)Bg * chunk_b, hipMemcpyHostToDevice, ctx->stream));
+            d_pcm = m->pcm_stage;
+        }
+        if ((rc = wm_model_reserve(ctx, Bg)) != WM_OK) break;
+        WM_HIP(hipEventRecord(ev[0], ctx->stream));
+        // 1. log-mel front end (f32 fast path), output stays in HBM
+        if ((rc = wm_frontend_run(&ctx->fe, &ctx->prof, ctx->stream, d_pcm, pcm_dtype, Bg, D.n_mels, m->mel_f32,
+                                  WM_F32)) != WM_OK) break;
+        WM_HIP(hipEventRecord(ev[1], ctx->stream));
+        // 2. encoder + cross-attention K/V
+        if ((rc = wm_model_encode_dev(ctx, m->mel_f32, Bg, nullptr)) != WM_OK) break;
+        if ((rc = wm_model_cross_kv(ctx, Bg)) != WM_OK) break;
+        WM_HIP(hipEventRecord(ev[2], ctx->stream));
+        // 3. greedy decode: prompt positions, then max_new generated tokens
+        if ((rc = wm_model_decode_begin(ctx, Bg)) != WM_OK) break;
+        std::vector<int32_t> pr((size_t)n_prompt * Bg);
+        for (int t = 0; t < n_prompt; ++t)
+            for (int b = 0; b < Bg; ++b) pr[(size_t)t * Bg + b] = prompt[t];
+        WM_HIP(hipMemcpyAsync(m->dcur, pr.data(), pr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        WM_HIP(hipStreamSynchronize(ctx->stream));
+        int *d_next = m->dcur + (size_t)n_prompt * Bg;  // generated token of the current step
+        for (int t = 0; t < n_prompt + max_new - 1 && rc == WM_OK; ++t) {
+            const bool gen = t >= n_prompt - 1;
+            const int *tok = t < n_prompt ? m->dcur + (size_t)t * Bg : d_next;
+            rc = wm_model_decode_step(ctx, Bg, t, tok, false, gen, 0, D.n_vocab - 1);
+            if (rc == WM_OK && gen)
+                rc = wm_argmax_reduce(ctx, m->dargmax, m->vpad / 16, Bg, d_next, m->dtokens, max_new,
+                                      t - (n_prompt - 1), nullptr, 0);
+        }
+        if (rc != WM_OK) break;
+        WM_HIP(hipEventRecord(ev[3], ctx->stream));
+        std::vector<int32_t> hist((size_t)Bg * max_new);
+        WM_HIP(hipMemcpyAsync(hist.data(), m->dtokens, hist.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        WM_HIP(hipStreamSynchronize(ctx->stream));
+        for (int b = 0; b < Bg; ++b) {
+            int len = max_new;
+            for (int i = 0; i < max_new; ++i)
+                if (eot >= 0 && hist[(size_t)b * max_new + i] == eot) { len = i + 1; break; }
+            for (int i = 0; i < max_new; ++i)
+                tokens_out[(size_t)(b0 + b) * max_new + i] = i < len ? hist[(size_t)b * max_new + i] : eot;
+            lens_out[b0 + b] = len;
+        }
+        float ms;
+        for (int i = 0; i < 3; ++i)
+            if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) ctx->stage_ms[i] += ms;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+// ------------------------------------------------------------------ per-kernel test hooks
+static int up(void **d, const void *h, size_t bytes, hipStream_t s) {
+    WM_HIP(hipMalloc(d, bytes + 512));
+    WM_HIP(hipMemsetAsync(*d, 0, bytes + 512, s));
+    if (h) WM_HIP(hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, s));
+    return WM_OK;
+}
+static void to_bf16(const float *in, std::vector<bf16_t> &out, size_t n) {
+    out.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t u;
+        memcpy(&u, &in[i], 4);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        out[i] = (bf16_t)(u >> 16);
+    }
+}
+static void from_bf16(const std::vector<bf16_t> &in, float *out) {
+    for (size_t i = 0; i < in.size(); ++i) {
+        uint32_t u = (uint32_t)in[i] << 16;
+        memcpy(&out[i], &u, 4);
+    }
+}
+
+extern "C" int wmdbg_gemm(wm_ctx *ctx, const float *A, const float *W, const float *bias, float *C, int M, int N,
+                          int K, int epi) {
+    WM_TRY(wm_ctx_make_current(ctx));
+    WM_REQUIRE(epi == EPI_F32 || epi == EPI_BIAS_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_F32, WM_ERR_INVALID,
+               "wmdbg_gemm: epilogue %d not exposed", epi);
+    std::vector<bf16_t> a16, w16;
+    to_bf16(A, a16, (size_t)M * K);
+    to_bf16(W, w16, (size_t)N * K);
+    void *dA, *dW, *dB = nullptr, *dC;
+    hipStream_t s = ctx->stream;
+    WM_TRY(up(&dA, a16.data(), a16.size() * 2, s));
+    WM_TRY(up(&dW, w16.data(), w16.size() * 2, s));
+    if (bias) WM_TRY(up(&dB, bias, (size_t)N * 4, s));
+    const bool f32out = (epi == EPI_F32 || epi == EPI_RESID_F32);
+    WM_TRY(up(&dC, epi == EPI_RESID_F32 ? C : nullptr, (size_t)M * N * (f32out ? 4 : 2), s));
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = (const bf16_t *)dA; g.a_rpb = (long)M + 1; g.a_rstride = K;
+    g.W = (const bf16_t *)dW; g.bias = (const float *)dB; g.C = dC;
+    g.c_rpb = (long)M + 1; g.c_rstride = N; g.M = M; g.N = N; g.K = K; g.epi = epi;
+    int rc = wm_gemm(ctx, g);
+    if (rc == WM_OK) {
+        if (f32out) {
+            WM_HIP(hipMemcpyAsync(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost, s));
+            WM_HIP(hipStreamSynchronize(s));
+        } else {
+            std::vector<bf16_t> c16((size_t)M * N);
+            WM_HIP(hipMemcpyAsync(c16.data(), dC, c16.size() * 2, hipMemcpyDeviceToHost, s));
+            WM_HIP(hipStreamSynchronize(s));
+            from_bf16(c16, C);
+        }
+    }
+    (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC);
+    if (dB) (void)hipFree(dB);
+    return rc;
+}
+
+extern "C" int wmdbg_layernorm(wm_ctx *ctx, const float *x, const float *g, const float *b, int rows, int d,
+                               float *out_f32, float *out_bf16_as_f32) {
+    WM_TRY(wm_ctx_make_current(ctx));
+    void *dx, *dg, *db, *of, *ob;
+    hipStream_t s = ctx->stream;
+    WM_TRY(up(&dx, x, (size_t)rows * d * 4, s));
+    WM_TRY(up(&dg, g, (size_t)d * 4, s));
+    WM_TRY(up(&db, b, (size_t)d * 4, s));
+    WM_TRY(up(&of, nullptr, (size_t)rows * d * 4, s));
+    WM_TRY(up(&ob, nullptr, (size_t)rows * d * 2, s));
+    int rc = wm_layernorm(ctx, (const float *)dx, (const float *)dg, (const float *)db, rows, d, (bf16_t *)ob, (float *)of);
+    if (rc == WM_OK) {
+        std::vector<bf16_t> t((size_t)rows * d);
+        WM_HIP(hipMemcpyAsync(out_f32, of, (size_t)rows * d * 4, hipMemcpyDeviceToHost, s));
+        WM_HIP(hipMemcpyAsync(t.data(), ob, t.size() * 2, hipMemcpyDeviceToHost, s));
+        WM_HIP(hipStreamSynchronize(s));
+        from_bf16(t, out_bf16_as_f32);
+    }
+    (void)hipFree(dx); (void)hipFree(dg); (void)hipFree(db); (void)hipFree(of); (void)hipFree(ob);
+    return rc;
+}
+
+// Encoder attention on host q, k, v given as f32 [B][S][H*64] each (rounded to bf16 inside).
+extern "C" int wmdbg_enc_attention(wm_ctx *ctx, const float *q, const float *k, const float *v, int B, int H, int S,
+                                   float *out) {
+    WM_TRY(wm_ctx_make_current(ctx));
+    const int d = H * 64, S_pad = ((S + 63) / 64) * 64;
+    const size_t M = (size_t)B * S;
+    std::vector<bf16_t> qk((M + 64) * 2 * d, 0), vt((size_t)B * H * 64 * S_pad, 0), tmp;
+    auto bf = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); };
+    for (size_t mrow = 0; mrow < M; ++mrow)
+        for (int j = 0; j < d; ++j) {
+            qk[mrow * 2 * d + j] = bf(q[mrow * d + j]);
+            qk[mrow * 2 * d + d + j] = bf(k[mrow * d + j]);
+        }
+    for (int b = 0; b < B; ++b)
+        for (int s = 0; s < S; ++s)
+            for (int j = 0; j < d; ++j)
+                vt[((size_t)(b * H + j / 64) * 64 + j % 64) * S_pad + s] = bf(v[((size_t)b * S + s) * d + j]);
+    void *dqk, *dvt, *datt;
+    hipStream_t st = ctx->stream;
+    WM_TRY(up(&dqk, qk.data(), qk.size() * 2, st));
+    WM_TRY(up(&dvt, vt.data(), vt.size() * 2, st));
+    WM_TRY(up(&datt, nullptr, M * d * 2, st));
+    int rc = wm_enc_attention(ctx, (const bf16_t *)dqk, (const bf16_t *)dvt, (bf16_t *)datt, B, H, S, S_pad, d);
+    if (rc == WM_OK) {
+        tmp.resize(M * d);
+        WM_HIP(hipMemcpyAsync(tmp.data(), datt, tmp.size() * 2, hipMemcpyDeviceToHost, st));
+        WM_HIP(hipStreamSynchronize(st));
+        from_bf16(tmp, out);
+    }
+    (void)hipFree(dqk); (void)hipFree(dvt); (void)hipFree(datt);
+    return rc;
+}
+
+// Skinny decode GEMV: out[B][N] = LN?(x)[B][K] . W[N][K]^T + bias (a_mode DA_LN or DA_BF16, epilogue DE_Q).
+extern "C" int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, const float *ln_b, const float *W,
+                              const float *bias, float *out, int B, int N, int K) {
+    WM_TRY(wm_ctx_make_current(ctx));
+    const int Npad = ((N + 15) / 16) * 16;
+    std::vector<bf16_t> w16, x16;
+    std::vector<float> wp((size_t)Npad * K, 0.f);
+    memcpy(wp.data(), W, (size_t)N * K * 4);
+    to_bf16(wp.data(), w16, wp.size());
+    void *dx, *dx16 = nullptr, *dg = nullptr, *db = nullptr, *dW, *dbias = nullptr, *dout;
+    hipStream_t s = ctx->stream;
+    WM_TRY(up(&dx, x, (size_t)B * K * 4, s));
+    WM_TRY(up(&dW, w16.data(), w16.size() * 2, s));
+    WM_TRY(up(&dout, nullptr, (size_t)B * N * 4, s));
+    if (bias) WM_TRY(up(&dbias, bias, (size_t)N * 4, s));
+    DecGemvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.N = N; a.K = K; a.W = (const bf16_t *)dW; a.bias = (const float *)dbias;
+    a.out_f32 = (float *)dout; a.ldo = N; a.epi = DE_Q;
+    if (ln_g) {
+        WM_TRY(up(&dg, ln_g, (size_t)K * 4, s));
+        WM_TRY(up(&db, ln_b, (size_t)K * 4, s));
+        a.a_mode = DA_LN; a.x = (const float *)dx; a.ln_g = (const float *)dg; a.ln_b = (const float *)db;
+    } else {
+        to_bf16(x, x16, (size_t)B * K);
+        WM_TRY(up(&dx16, x16.data(), x16.size() * 2, s));
+        a.a_mode = DA_BF16; a.a_bf16 = (const bf16_t *)dx16;
+    }
+    int rc = wm_dec_gemv(ctx, a);
+    if (rc == WM_OK) {
+        WM_HIP(hipMemcpyAsync(out, dout, (size_t)B * N * 4, hipMemcpyDeviceToHost, s));
+        WM_HIP(hipStreamSynchronize(s));
+    }
+    void *fr[] = {dx, dx16, dg, db, dW, dbias, dout};
+    for (void *p : fr)
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
+// Single-query attention: q f32 [B][H*64], k/v f32 [B][H][T][64] (rounded to bf16), first
+// n_keys positions, `nsplit` flash-decoding splits; out f32 [B][H*64] (partials combined on host).
+extern "C" int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, const float *v, int B, int H, int T,
+                                   int n_keys, int nsplit, float *out) {
+    WM_TRY(wm_ctx_make_current(ctx));
+    std::vector<bf16_t> k16, v16;
+    to_bf16(k, k16, (size_t)B * H * T * 64);
+    to_bf16(v, v16, (size_t)B * H * T * 64);
+    void *dq, *dk, *dv, *dp;
+    hipStream_t s = ctx->stream;
+    WM_TRY(up(&dq, q, (size_t)B * H * 64 * 4, s));
+    WM_TRY(up(&dk, k16.data(), k16.size() * 2, s));
+    WM_TRY(up(&dv, v16.data(), v16.size() * 2, s));
+    WM_TRY(up(&dp, nullptr, (size_t)B * H * nsplit * 66 * 4, s));
+    int rc = wm_dec_attention(ctx, (const float *)dq, (const bf16_t *)dk, (const bf16_t *)dv, B, H, T, n_keys, nsplit,
+                              (float *)dp);
+    if (rc == WM_OK) {
+        std::vector<float> part((size_t)B * H * nsplit * 66);
+        WM_HIP(hipMemcpyAsync(part.data(), dp, part.size() * 4, hipMemcpyDeviceToHost, s));
+        WM_HIP(hipStreamSynchronize(s));
+        for (int bh = 0; bh < B * H; ++bh) {
+            const float *pp = &part[(size_t)bh * nsplit * 66];
+            float Mx = -1e30f;
+            for (int i = 0; i < nsplit; ++i) Mx = pp[i * 66] > Mx ? pp[i * 66] : Mx;
+            double den = 0;
+            double num[64] = {0};
+            for (int i = 0; i < nsplit; ++i) {
+                const double w = exp((double)pp[i * 66] - Mx);
+                den += w * pp[i * 66 + 1];
+                for (int e = 0; e < 64; ++e) num[e] += w * pp[i * 66 + 2 + e];
+            }
+            for (int e = 0; e < 64; ++e) out[(size_t)bh * 64 + e] = (float)(num[e] / den);
+        }
+    }
+    (void)hipFree(dq); (void)hipFree(dk); (void)hipFree(dv); (void)hipFree(dp);
+    return rc;
 }

@@ -1,0 +1,171 @@
+"""GPU unit tests: each hand-written HIP kernel of boundary #2 against a plain fp32/fp64
+numpy / torch restatement of the same op, through the wmdbg_* hooks of the C ABI
+(include/whisper_mi355x_debug.h).  Inputs are rounded to bf16 the same way HBM holds them,
+so the tolerances below measure the kernel (fp32 accumulate, bf16 outputs), not the input
+quantisation.  Asymmetric operands everywhere: a transposed fragment layout must fail."""
+import ctypes
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+W = importlib.import_module("openai_whisper_coreml_amd.weights")
+
+
+def bf(x):
+    return W.bf16_round_f32(np.ascontiguousarray(x, dtype=np.float32))
+
+
+def P(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.binding.Context()
+    lib = c.lib
+    vp, ip = ctypes.c_void_p, ctypes.c_int
+    lib.wmdbg_gemm.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, ip]
+    lib.wmdbg_layernorm.argtypes = [vp, vp, vp, vp, ip, ip, vp, vp]
+    lib.wmdbg_enc_attention.argtypes = [vp, vp, vp, vp, ip, ip, ip, vp]
+    lib.wmdbg_dec_gemv.argtypes = [vp, vp, vp, vp, vp, vp, vp, ip, ip, ip]
+    lib.wmdbg_dec_attention.argtypes = [vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
+    yield c
+    c.close()
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 256, 192), (1500, 128, 1280),
+                                   (77, 512, 64)])
+def test_gemm_f32_out(ctx, M, N, K):
+    rng = np.random.default_rng(M + N + K)
+    A = bf(rng.standard_normal((M, K)))
+    Wt = bf(rng.standard_normal((N, K)) * 0.1 + np.linspace(-0.05, 0.05, N)[:, None])  # asymmetric
+    bias = rng.standard_normal(N).astype(np.float32)
+    C = np.zeros((M, N), np.float32)
+    st = ctx.lib.wmdbg_gemm(ctx.handle, P(A), P(Wt), P(bias), P(C), M, N, K, 6)
+    assert st == 0, ctx.lib.wm_last_error()
+    ref = A.astype(np.float64) @ Wt.astype(np.float64).T + bias
+    assert np.abs(C - ref).max() <= 2e-4 * np.abs(ref).max(), (np.abs(C - ref).max(), np.abs(ref).max())
+
+
+def test_gemm_identity_asymmetric(ctx):
+    """A = I picks rows of W^T: any row<->col swap in the C write shows up exactly."""
+    M = N = K = 128
+    A = np.eye(M, K, dtype=np.float32)
+    Wt = bf(np.arange(N * K, dtype=np.float32).reshape(N, K) % 251 - 100.0)
+    C = np.zeros((M, N), np.float32)
+    assert ctx.lib.wmdbg_gemm(ctx.handle, P(A), P(Wt), None, P(C), M, N, K, 6) == 0
+    assert np.array_equal(C, Wt.T)
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2])
+def test_gemm_epilogues(ctx, epi):
+    rng = np.random.default_rng(epi)
+    M, N, K = 200, 256, 128
+    A = bf(rng.standard_normal((M, K)))
+    Wt = bf(rng.standard_normal((N, K)) * 0.1)
+    bias = rng.standard_normal(N).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    C = C0.copy()
+    assert ctx.lib.wmdbg_gemm(ctx.handle, P(A), P(Wt), P(bias), P(C), M, N, K, epi) == 0
+    lin = A.astype(np.float64) @ Wt.astype(np.float64).T + bias
+    if epi == 0:
+        ref, tol = lin, 8e-3          # bf16 output: 2^-8 relative
+    elif epi == 1:
+        ref, tol = torch.nn.functional.gelu(torch.from_numpy(lin)).numpy(), 8e-3
+    else:
+        ref, tol = C0 + lin, 1e-5
+    assert np.abs(C - ref).max() <= tol * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("rows,d", [(5, 128), (1500, 384), (33, 768), (64, 1280)])
+def test_layernorm(ctx, rows, d):
+    rng = np.random.default_rng(d)
+    x = (rng.standard_normal((rows, d)) * 3 + 1.5).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    o32 = np.zeros_like(x)
+    o16 = np.zeros_like(x)
+    assert ctx.lib.wmdbg_layernorm(ctx.handle, P(x), P(g), P(b), rows, d, P(o32), P(o16)) == 0
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(x).double(), (d,), torch.from_numpy(g).double(),
+                                         torch.from_numpy(b).double(), 1e-5).numpy()
+    assert np.abs(o32 - ref).max() <= 2e-5
+    assert np.abs(o16 - ref).max() <= 2 ** -8 * np.abs(ref).max() + 1e-6
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 2, 1500), (2, 1, 200), (1, 3, 64), (1, 1, 129)])
+def test_encoder_attention(ctx, B, H, S):
+    rng = np.random.default_rng(S)
+    d = H * 64
+    q = bf(rng.standard_normal((B, S, d)))
+    k = bf(rng.standard_normal((B, S, d)))
+    v = bf(rng.standard_normal((B, S, d)) + np.linspace(-1, 1, d)[None, None, :])
+    # force an online-softmax rescale late in the sequence: one key that dominates one query
+    k[0, S - 3, :64] = q[0, 5, :64] * 3.0
+    out = np.zeros((B, S, d), np.float32)
+    assert ctx.lib.wmdbg_enc_attention(ctx.handle, P(q), P(k), P(v), B, H, S, P(out)) == 0
+    tq, tk, tv = (torch.from_numpy(a).double().view(B, S, H, 64).permute(0, 2, 1, 3) for a in (q, k, v))
+    w = torch.softmax(tq @ tk.transpose(-1, -2) / 8.0, dim=-1)
+    ref = (w @ tv).permute(0, 2, 1, 3).reshape(B, S, d).numpy()
+    assert np.abs(out - ref).max() <= 2e-2 * np.abs(ref).max(), np.abs(out - ref).max()
+    assert rel(out, ref) <= 6e-3
+
+
+@pytest.mark.parametrize("B,N,K,ln", [(8, 1280, 1280, True), (8, 1280, 5120, False), (1, 384, 384, True),
+                                      (16, 100, 512, True), (3, 1030, 64, False), (8, 3840, 1280, True),
+                                      (2, 128, 1536, False)])
+def test_decode_gemv(ctx, B, N, K, ln):
+    rng = np.random.default_rng(N + K)
+    x = (rng.standard_normal((B, K)) * 2 + 0.3).astype(np.float32)
+    Wt = bf(rng.standard_normal((N, K)) * 0.05 + np.linspace(-0.02, 0.02, N)[:, None])
+    bias = rng.standard_normal(N).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(K)).astype(np.float32)
+    out = np.zeros((B, N), np.float32)
+    st = ctx.lib.wmdbg_dec_gemv(ctx.handle, P(x), P(g) if ln else None, P(b) if ln else None, P(Wt), P(bias),
+                                P(out), B, N, K)
+    assert st == 0, ctx.lib.wm_last_error()
+    if ln:
+        a = torch.nn.functional.layer_norm(torch.from_numpy(x).double(), (K,), torch.from_numpy(g).double(),
+                                           torch.from_numpy(b).double(), 1e-5).numpy()
+        a = bf(a).astype(np.float64)   # the kernel feeds the matrix pipe bf16 activations
+    else:
+        a = bf(x).astype(np.float64)
+    ref = a @ Wt.astype(np.float64).T + bias
+    # LN path: our bf16 rounding of LN(x) can differ from the kernel's by one ulp on a few elements
+    tol = (4e-3 if ln else 2e-4) * np.abs(ref).max()
+    assert np.abs(out - ref).max() <= tol, (np.abs(out - ref).max(), np.abs(ref).max())
+
+
+@pytest.mark.parametrize("B,H,T,n_keys,nsplit", [(2, 2, 448, 1, 1), (2, 2, 448, 37, 1), (1, 3, 448, 448, 1),
+                                                 (2, 2, 1500, 1500, 4), (1, 1, 1500, 1500, 3)])
+def test_decode_attention(ctx, B, H, T, n_keys, nsplit):
+    rng = np.random.default_rng(T + n_keys)
+    q = rng.standard_normal((B, H * 64)).astype(np.float32)
+    k = bf(rng.standard_normal((B, H, T, 64)))
+    v = bf(rng.standard_normal((B, H, T, 64)) + np.linspace(-1, 1, 64))
+    k[:, :, n_keys:] = 1e3    # poison positions the kernel must not read into the softmax
+    out = np.zeros((B, H * 64), np.float32)
+    st = ctx.lib.wmdbg_dec_attention(ctx.handle, P(q), P(k), P(v), B, H, T, n_keys, nsplit, P(out))
+    assert st == 0, ctx.lib.wm_last_error()
+    tq = torch.from_numpy(q).double().view(B, H, 1, 64)
+    tk = torch.from_numpy(k[:, :, :n_keys]).double()
+    tv = torch.from_numpy(v[:, :, :n_keys]).double()
+    w = torch.softmax(tq @ tk.transpose(-1, -2) / 8.0, dim=-1)
+    ref = (w @ tv).reshape(B, H * 64).numpy()
+    assert np.abs(out - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_decode_attention_rejects_oversized_split(ctx):
+    q = np.zeros((1, 64), np.float32)
+    k = np.zeros((1, 1, 1500, 64), np.float32)
+    out = np.zeros((1, 64), np.float32)
+    assert ctx.lib.wmdbg_dec_attention(ctx.handle, P(q), P(k), P(k), 1, 1, 1500, 1500, 2, P(out)) == 1
+    assert b"512-key" in ctx.lib.wm_last_error()

@@ -1,0 +1,237 @@
+"""GPU parity tests for boundary #2 (encoder / decoder / greedy decode) through the C ABI,
+against the fp32 PyTorch oracle (oracle/whisper_ref.py) on identical synthetic weights.
+
+Tolerances (stated here, as BASELINE.md asks): the HIP path computes GEMM inputs, K/V caches
+and attention probabilities in bf16 with fp32 accumulation, fp32 LayerNorm / softmax /
+residual stream.  Against the all-fp32 oracle that gives
+    encoder output (post ln_post)  rel-L2 <= 5e-3   (measured 3e-4 .. 1.1e-3)
+    teacher-forced logits          rel-L2 <= 1e-2   (measured 3e-3 .. 4e-3)
+and arg-max decisions are checked by margin: the token the GPU picks must be within
+0.05 logit units of the oracle's maximum (exact equality whenever the oracle's top-2 gap is
+larger than that)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import logmel_np as L
+from oracle import whisper_ref as R
+
+pytestmark = pytest.mark.gpu
+
+W = importlib.import_module("openai_whisper_coreml_amd.weights")
+ENC_TOL = 5e-3
+LOGIT_TOL = 1e-2
+MARGIN = 0.05
+
+
+def nontrivial_ln(sd, seed=0):
+    """Synthetic weights have LN gamma=1, beta=0; perturb so LN parameters are exercised."""
+    rng = np.random.default_rng(seed)
+    for k in sd:
+        if "ln" in k and k.endswith("weight"):
+            sd[k] = (1 + 0.1 * rng.standard_normal(sd[k].shape)).astype(np.float32)
+        if "ln" in k and k.endswith("bias"):
+            sd[k] = (0.1 * rng.standard_normal(sd[k].shape)).astype(np.float32)
+    return sd
+
+
+@pytest.fixture(scope="module")
+def tiny(pkg):
+    dims = dict(R.TINY_DIMS)
+    sd_np = nontrivial_ln(W.synthetic_state_dict(dims, seed=11))
+    ctx = pkg.binding.Context(dims)
+    ctx.load_state_dict(sd_np)
+    ctx.finalize()
+    yield dims, sd_np, R.to_torch(sd_np), ctx
+    ctx.close()
+
+
+def mels(ctx, n, start=0):
+    pcm = np.stack([L.synth_chunk(start + i) for i in range(n)])
+    return pcm, ctx.logmel(pcm, out_dtype=np.float32)
+
+
+def test_device_synthetic_generator_is_bit_identical(pkg):
+    dims = dict(R.TINY_DIMS)
+    sd_np = W.synthetic_state_dict(dims, seed=5)
+    ctx = pkg.binding.Context(dims)
+    ctx.init_synthetic(5)
+    ctx.finalize()
+    for name, shape, kind in W.tensor_specs(dims):
+        got = ctx.get_tensor(name, shape)
+        if kind == W.K_SINUSOID:
+            assert np.abs(got - sd_np[name]).max() <= 1e-6, name
+        else:
+            assert np.array_equal(got, sd_np[name]), name
+    ctx.close()
+
+
+def test_set_get_roundtrip_and_flat_file(pkg, tiny, tmp_path):
+    dims, sd_np, _, ctx = tiny
+    for name in ("encoder.conv1.weight", "encoder.conv2.weight", "decoder.blocks.1.cross_attn.key.weight",
+                 "decoder.blocks.0.attn.value.bias", "decoder.token_embedding.weight"):
+        got = ctx.get_tensor(name, sd_np[name].shape)
+        want = W.bf16_round_f32(sd_np[name]) if name.endswith("weight") else sd_np[name]
+        assert np.array_equal(got, want), name
+    path = os.path.join(tmp_path, "tiny.wm")
+    W.save_flat(path, dims, sd_np)
+    d2, sd2 = W.load_flat(path)
+    assert d2 == dims and all(np.array_equal(sd2[k], sd_np[k]) for k in sd_np)
+    c2 = pkg.binding.Context(dims)
+    c2.load_weights(path)
+    c2.finalize()
+    assert np.array_equal(c2.get_tensor("decoder.ln.weight", (128,)), sd_np["decoder.ln.weight"])
+    c2.close()
+
+
+def test_encoder_parity(tiny):
+    dims, _, sd, ctx = tiny
+    _, mel = mels(ctx, 2)
+    got = ctx.encode_mel(mel)
+    want = R.encode(sd, dims, mel).numpy()
+    e = R.rel_l2(got, want)
+    print("encoder rel-L2", e)
+    assert got.shape == (2, 1500, 128) and e <= ENC_TOL
+
+
+def test_encoder_batch_independence(tiny):
+    dims, _, _, ctx = tiny
+    _, mel = mels(ctx, 3)
+    all3 = ctx.encode_mel(mel)
+    one = ctx.encode_mel(mel[1:2])
+    assert np.array_equal(all3[1], one[0])   # chunks are independent units: bit-identical
+
+
+def test_decode_logits_parity(tiny):
+    dims, _, sd, ctx = tiny
+    _, mel = mels(ctx, 2)
+    xa = R.encode(sd, dims, mel).numpy()     # same fp32 xa for both sides
+    toks = np.array([[1, 7, 300, 1023, 5, 9], [4, 4, 900, 17, 0, 511]], np.int32)
+    got = ctx.decode_logits(toks, xa)
+    want = R.decode_logits(sd, dims, toks, xa).numpy()
+    e = R.rel_l2(got, want)
+    print("logits rel-L2", e, "std", want.std())
+    assert got.shape == (2, 6, 1024) and e <= LOGIT_TOL
+    # T = 1 is the reference's exported decoder shape (whisper_to_cml.py:28)
+    got1 = ctx.decode_logits(toks[:, :1], xa)
+    assert np.array_equal(got1[:, 0], got[:, 0])
+
+
+def _check_choice(ref_logits_row, gpu_choice):
+    gap = float(ref_logits_row.max() - ref_logits_row[gpu_choice])
+    assert gap <= MARGIN, "GPU picked %d, oracle gap %g" % (gpu_choice, gap)
+
+
+def test_detect_language_mirrors_swift(tiny):
+    """Whisper.swift:33-40 with the tiny vocabulary: SOT=10, languages 20..118 (99 ids)."""
+    dims, _, sd, ctx = tiny
+    _, mel = mels(ctx, 3)
+    xa = R.encode(sd, dims, mel).numpy()
+    got = ctx.detect_language(xa, sot=10, lang_first=20, lang_last=118)
+    _, conf = R.detect_language(sd, dims, xa, sot=10, lang_first=20, lang_last=118)
+    assert got.shape == (3,) and got.min() >= 0 and got.max() <= 98
+    for b in range(3):
+        _check_choice(conf[b], int(got[b]))
+
+
+def test_greedy_transcribe_end_to_end(tiny):
+    dims, _, sd, ctx = tiny
+    pcm, mel = mels(ctx, 2, start=3)
+    prompt = [10, 21, 3]
+    toks, lens = ctx.transcribe_greedy(pcm, prompt, 12, eot=-1)
+    assert toks.shape == (2, 12) and lens.tolist() == [12, 12]
+    xa = ctx.encode_mel(mel)                          # the GPU's own encoder output
+    for b in range(2):
+        seq = np.concatenate([prompt, toks[b]])[None, :-1]
+        ref = R.decode_logits(sd, dims, seq, xa[b:b + 1]).numpy()[0]
+        for i in range(12):                           # every greedy choice, teacher-forced on the GPU's history
+            _check_choice(ref[len(prompt) - 1 + i], int(toks[b, i]))
+    # int16 PCM input gives the same tokens as the float path modulo quantisation of the audio
+    s16 = np.round(pcm * 32767).astype(np.int16)
+    toks16, _ = ctx.transcribe_greedy(s16, prompt, 4, eot=-1)
+    assert toks16.shape == (2, 4)
+    # eot handling: stop at the first generated token equal to eot, pad with eot
+    eot = int(toks[0, 2])
+    t2, l2 = ctx.transcribe_greedy(pcm, prompt, 12, eot=eot)
+    first = int(np.argmax(toks[0] == eot))
+    assert l2[0] == first + 1 and (t2[0, first:] == eot).all() and (t2[0, :first] == toks[0, :first]).all()
+
+
+def test_greedy_is_deterministic_and_batch_invariant(tiny):
+    dims, _, _, ctx = tiny
+    pcm, _ = mels(ctx, 3, start=6)
+    a, _ = ctx.transcribe_greedy(pcm, [10], 8)
+    b, _ = ctx.transcribe_greedy(pcm, [10], 8)
+    c, _ = ctx.transcribe_greedy(pcm[1:2], [10], 8)
+    assert np.array_equal(a, b) and np.array_equal(a[1], c[0])
+
+
+def test_swift_surface_mirror(pkg):
+    """struct Whisper (Whisper.swift:11-41): init -> encode(audio) -> decode(features)."""
+    dims = dict(R.TINY_DIMS, n_vocab=51865)
+    sd_np = W.synthetic_state_dict(dims, seed=2)
+    wh = pkg.Whisper(dims, state_dict=sd_np)
+    audio = np.zeros(480000, np.float64)
+    x = L.synth_chunk(1)
+    audio[:160000] = x[:160000]                       # ContentView.swift:57-60: 10 s, zero-padded
+    enc = wh.encode(audio)
+    assert enc.shape == (1, 1500, 128)
+    lang = wh.decode(enc)
+    assert lang in pkg.Whisper.LANGUAGES and len(pkg.Whisper.LANGUAGES) == 99
+    sd = R.to_torch(sd_np)
+    idx, conf = R.detect_language(sd, dims, enc)
+    _check_choice(conf[0], pkg.Whisper.LANGUAGES.index(lang))
+    wh.ctx.close()
+
+
+def test_tiny_en_dimensions(pkg):
+    """BASELINE.json configs[1] geometry (tiny.en: d 384, 6 heads, 4+4 layers, vocab 51864)."""
+    dims = pkg.binding.MODEL_DIMS["tiny.en"]
+    ctx = pkg.binding.Context(dims)
+    ctx.init_synthetic(7)
+    ctx.finalize()
+    sd = R.to_torch({n: ctx.get_tensor(n, s) for n, s, _ in W.tensor_specs(dims)})
+    pcm, mel = mels(ctx, 1)
+    got = ctx.encode_mel(mel)
+    want = R.encode(sd, dims, mel).numpy()
+    e = R.rel_l2(got, want)
+    print("tiny.en encoder rel-L2", e)
+    assert e <= ENC_TOL
+    toks = np.array([[50257, 50362, 100, 2000]], np.int32)
+    lg = ctx.decode_logits(toks, want)
+    ref = R.decode_logits(sd, dims, toks, want).numpy()
+    e2 = R.rel_l2(lg, ref)
+    print("tiny.en logits rel-L2", e2)
+    assert e2 <= LOGIT_TOL
+    ctx.close()
+
+
+def test_error_paths(pkg):
+    dims = dict(R.TINY_DIMS)
+    ctx = pkg.binding.Context(dims)
+    with pytest.raises(pkg.binding.WhisperError, match="never set"):
+        ctx.finalize()
+    with pytest.raises(pkg.binding.WhisperError, match="unknown tensor"):
+        ctx.set_tensor("encoder.nope", np.zeros(4, np.float32))
+    with pytest.raises(pkg.binding.WhisperError, match="expected"):
+        ctx.set_tensor("encoder.conv1.bias", np.zeros(4, np.float32))
+    with pytest.raises(pkg.binding.WhisperError, match="not finalised"):
+        ctx.encode_mel(np.zeros((1, 80, 3000), np.float32))
+    ctx.init_synthetic(1)
+    ctx.finalize()
+    xa = np.zeros((1, 1500, 128), np.float32)
+    with pytest.raises(pkg.binding.WhisperError, match="token id"):
+        ctx.decode_logits(np.array([[5000]], np.int32), xa)
+    with pytest.raises(pkg.binding.WhisperError, match="T must be"):
+        ctx.decode_logits(np.zeros((1, 449), np.int32), xa)
+    with pytest.raises(pkg.binding.WhisperError, match="context"):
+        ctx.transcribe_greedy(np.zeros((1, 480000), np.float32), [1, 2], 447)
+    ctx.close()
+    fe = pkg.binding.Context()
+    with pytest.raises(pkg.binding.WhisperError, match="without a model"):
+        fe.finalize()
+    fe.close()
+    with pytest.raises(pkg.binding.WhisperError):
+        pkg.binding.Context(dict(dims, n_audio_state=100))
