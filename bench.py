@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X: audio-sec/s (+ decoder tok/s), Whisper-large-v2
+geometry, 30 s chunks, batch 8 per GPU (BASELINE.json configs[3]), chunk-parallel over N GPUs.
+
+One "step" = one pass of the hot path over one batch of synthetic 16 kHz audio that is
+already resident in HBM (int16 PCM): log-mel front end -> encoder -> cross-attention K/V
+-> KV-cached greedy decode of 224 tokens (n_text_ctx // 2, EOT suppressed so the work is
+fixed) -> tokens on the host.  Everything runs through the C ABI of libwhisper_mi355x.so
+(no torch compute; torch is only used for torch.distributed / RCCL at N > 1).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model large-v2] [--batch 8]
+
+N > 1: launched by torch.distributed.run, one rank per GPU; each rank owns its own chunks
+(weak scaling, no data-path collective) and the token streams are all-gathered over RCCL
+inside the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+
+
+def synth_pcm16(chunk_idx):
+    """BASELINE.md synthetic audio: rng(1234+idx), clip(0.1 N(0,1)), int16 = round(x * 32767)."""
+    rng = np.random.default_rng(1234 + chunk_idx)
+    x = np.clip(0.1 * rng.standard_normal(480000), -1.0, 1.0).astype(np.float32)
+    return np.round(x * 32767).astype(np.int16)
+
+
+def structured_pcm16():
+    n = np.arange(480000, dtype=np.float64)
+    x = 0.3 * np.cos(2 * np.pi * 1000 * n / 16000) + 0.2 * np.cos(2 * np.pi * 2400 * n / 16000) \
+        + 0.1 * np.cos(2 * np.pi * 5600 * n / 16000)
+    return np.round(x * 32767).astype(np.int16)
+
+
+def algorithmic_work(family, dims, B):
+    """Algorithmic bytes / flops of ONE launch of a kernel family (SURVEY.md 8d formulas)."""
+    d, L, H, V = dims["n_text_state"], dims["n_text_layer"], dims["n_text_head"], dims["n_vocab"]
+    M = B * 1500
+    gemv = {"dec_gemv_ln_qkv": 3 * d * d, "dec_gemv_attn_out": d * d, "dec_gemv_ln_q": d * d,
+            "dec_gemv_ln_fc1": 4 * d * d, "dec_gemv_fc2": 4 * d * d, "dec_gemv_ln_logits": V * d}
+    if family in gemv:
+        return "hbm", 2.0 * gemv[family]                      # bf16 weights streamed once
+    if family == "dec_attn_cross":
+        return "hbm", B * 2.0 * 1500 * d * 2                  # cached K and V of one layer
+    if family == "dec_attn_self":
+        return "hbm", B * 2.0 * 112 * d * 2                   # mean context ~ 224/2 positions
+    flops = {"gemm_qkv_enc": 2.0 * M * 3 * d * d, "gemm_gelu_bf16": 2.0 * M * 4 * d * d,
+             "gemm_resid_f32": 2.0 * M * d * d * 2.5,         # mean of out-proj (d*d) and fc2 (4d*d)
+             "gemm_xkv": 2.0 * M * 2 * d * d, "gemm_conv2_f32": 2.0 * M * 3 * d * d,
+             "enc_attention": 4.0 * B * 1500 * 1500 * d}
+    if family in flops:
+        return "mfma", flops[family]
+    return None, 0.0
+
+
+def effective_cores():
+    """Host cores this process may actually use (affinity mask and cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(ctx, dims, pcm16_chunk, prompt):
+    """CPU oracle timed on this box's host cores (a reported baseline, not the target):
+    C restatement of the Rust front end (1 thread, as the crate is single-threaded) +
+    PyTorch fp32 restatement of the model, same synthetic weights pulled back from HBM.
+    BOUNDED sample (~10-30 s): 1 chunk; front end in full; conv stem + the first 2 of the
+    encoder layers; cross-K/V and 2 decode steps (batch 1) of the first 2 decoder layers;
+    per-layer times are extrapolated to the full depth and 224 tokens."""
+    import subprocess
+    import importlib
+    import torch
+    from oracle import whisper_ref as R
+    W = importlib.import_module("openai_whisper_coreml_amd.weights")
+    so = os.path.join(ROOT, "oracle", "liboracle_logmel.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    lib = ctypes.CDLL(so)
+    cores = effective_cores()
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    x = (pcm16_chunk.astype(np.float32) / 32768.0)[None, :]
+    out = np.zeros((1, 80, 3000))
+    t0 = time.perf_counter()
+    lib.oracle_logmel_batch_f32(x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(1),
+                                out.ctypes.data_as(ctypes.c_void_p))
+    t_fe = time.perf_counter() - t0
+    nl = 2
+    sub = dict(dims, n_audio_layer=nl, n_text_layer=nl)
+    keep = {n: s for n, s, _ in W.tensor_specs(sub)}
+    sd = {n: torch.from_numpy(ctx.get_tensor(n, s)) for n, s in keep.items()}
+    mel = out.astype(np.float32)
+    if dims["n_mels"] != 80:
+        mel = np.zeros((1, dims["n_mels"], 3000), np.float32)
+    one = dict(sub, n_audio_layer=1)
+    t0 = time.perf_counter(); R.encode(sd, one, mel); t1 = time.perf_counter() - t0
+    t0 = time.perf_counter(); xa = R.encode(sd, sub, mel); t2 = time.perf_counter() - t0
+    per_enc = max(t2 - t1, 1e-9)
+    t_enc = max(t1 - per_enc, 0.0) + per_enc * dims["n_audio_layer"]
+    t0 = time.perf_counter()
+    for i in range(nl):
+        p = f"decoder.blocks.{i}.cross_attn"
+        torch.nn.functional.linear(xa, sd[p + ".key.weight"])
+        torch.nn.functional.linear(xa, sd[p + ".value.weight"], sd[p + ".value.bias"])
+    t_xkv = (time.perf_counter() - t0) / nl * dims["n_text_layer"]
+    n_steps = 2
+    t0 = time.perf_counter()
+    R.greedy(sd, sub, xa, prompt, n_steps, eot=-1)
+    t_dec = time.perf_counter() - t0
+    t_xkv2 = t_xkv / dims["n_text_layer"] * nl
+    # a step = L layers + the logits GEMV; the 2-layer run over-counts the (shared) logits part,
+    # so this extrapolation is slightly pessimistic for the CPU
+    t_step = max(t_dec - t_xkv2, 1e-9) / n_steps / nl * dims["n_text_layer"]
+    total = t_fe + t_enc + t_xkv + 224 * t_step
+    return {"value": 30.0 / total, "unit": "audio-sec/s", "cores": threads if cores >= threads else cores,
+            "kind": "port",
+            "sample": "1 chunk on %d host threads (%d usable cores): C front-end restatement (1 thread) %.3f s; torch-fp32 "
+                      "conv stem + 2 encoder layers timed, x%d layers => encoder %.2f s; cross-K/V %.2f s; 2 decode steps of "
+                      "2 decoder layers at batch 1 timed => %.3f s/step, 224 steps extrapolated.  The Rust crate and "
+                      "the CoreML models themselves cannot run here." % (threads, cores, t_fe, dims["n_audio_layer"], t_enc,
+                                                                       t_xkv, t_step),
+            "decoder_tok_per_s": 1.0 / t_step}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="large-v2")
+    ap.add_argument("--batch", type=int, default=8, help="30 s chunks per GPU per step")
+    ap.add_argument("--new-tokens", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")   # nccl == RCCL on ROCm (xGMI inside a node)
+
+    import openai_whisper_coreml_amd as pkg
+    B = pkg.binding
+    dims = B.MODEL_DIMS[args.model]
+    ctx = B.Context(dims, device=local_rank)
+    ctx.init_synthetic(20240928)
+    ctx.finalize()
+
+    nb = args.batch
+    chunks = [structured_pcm16() if i == 0 else synth_pcm16(rank * nb + i) for i in range(nb)]
+    pcm = np.stack(chunks)
+    d_pcm = ctx.to_device(pcm)
+    sot, eot = 50258, 50257
+    prompt = [sot, sot + 1, sot + 101, sot + 105] if dims["n_vocab"] >= 51865 else [50257, 50362]
+    max_new = args.new_tokens
+
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        toks, lens = ctx.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE,
+                                           pcm_dtype=B.WM_I16, B=nb)
+        if world > 1:
+            t = torch.from_numpy(np.concatenate([lens[:, None], toks], axis=1)).cuda()
+            out = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(out, t)               # [1 + max_new] int32 per chunk per rank
+            gathered = out
+        return toks, lens
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    stage = np.zeros(3)
+    for _ in range(args.steps):
+        toks, lens = step()
+        stage += ctx.last_stage_ms()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64).cuda()
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # second pass of the SAME steps with per-launch HIP events on the launch stream
+    roof = None
+    prof = {}
+    if rank == 0:
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(args.steps):
+            ctx.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE, pcm_dtype=B.WM_I16, B=nb)
+        prof = ctx.profile()
+        ctx.profile_enable(False)
+        if prof:
+            dom = max(prof, key=lambda k: prof[k]["ms"])
+            kind, work = algorithmic_work(dom, dims, nb)
+            avg_s = prof[dom]["ms"] / prof[dom]["n"] * 1e-3
+            if kind == "hbm":
+                ach = work / avg_s / 1e9
+                roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_us": avg_s * 1e6,
+                        "alg_bytes_per_launch": work, "launches": prof[dom]["n"]}
+            elif kind == "mfma":
+                ach = work / avg_s / 1e12
+                roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TF, "traffic": None,
+                        "avg_us": avg_s * 1e6, "alg_flops_per_launch": work, "launches": prof[dom]["n"]}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(ctx, dims, pcm[1], prompt)
+        except Exception as e:  # the baseline leg must never take the GPU number down with it
+            cpu = {"value": None, "unit": "audio-sec/s", "cores": os.cpu_count(), "kind": "port",
+                   "sample": "failed: %r" % (e,)}
+
+    if rank == 0:
+        total_audio = 30.0 * nb * world * args.steps
+        dec_steps = len(prompt) + max_new - 1
+        stage_s = stage / 1e3 / max(args.steps, 1)
+        fams = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["n"] / args.steps,
+                    "avg_us": v["ms"] / v["n"] * 1e3} for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        line = {
+            "metric": "audio-sec/s (RTF) + decoder tok/s, Whisper-large-v2 30s chunks, 1->8 GPU",
+            "value": total_audio / dt,
+            "unit": "audio-sec/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "whisper-%s geometry, random-init weights, %d x 30 s int16 chunks per GPU "
+                                   "resident in HBM, greedy %d new tokens (EOT suppressed), prompt %d tokens"
+                                   % (args.model, nb, max_new, len(prompt)),
+                       "chunks_per_gpu": nb, "new_tokens": max_new, "parallelism": "chunk-dp%d" % world},
+            "rtf": dt / total_audio,
+            "decoder_tok_per_s": (nb * world * max_new) / max(stage_s[2], 1e-9),
+            "decoder_ms_per_step": stage_s[2] * 1e3 / dec_steps,
+            "stage_ms": {"frontend": stage_s[0] * 1e3, "encoder_xkv": stage_s[1] * 1e3, "decode": stage_s[2] * 1e3},
+            "roofline": roof,
+            "roofline_note": "per-launch HIP events (hipEventRecord on the launch stream) in a second pass of the same steps",
+            "cpu_baseline": cpu,
+            "kernel_families": fams,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

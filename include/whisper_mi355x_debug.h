@@ -36,7 +36,8 @@ int wmdbg_enc_attention(wm_ctx *ctx, const float *q, const float *k, const float
 /* Decode-step skinny GEMM: out[B][N] = (ln_g ? LayerNorm(x) : x) . W[N][K]^T + bias; B <= 16. */
 int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, const float *ln_b, const float *W,
                    const float *bias, float *out, int B, int N, int K);
-/* Single-query attention over a cache: q [B][H*64], k/v [B][H][T][64], keys 0..n_keys-1. */
+/* Single-query attention over a cache: q [B][H*64], k/v [B][H][T][64], keys 0..n_keys-1;
+ * out = the bf16 head outputs widened to f32.  nsplit in 1..8. */
 int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, const float *v, int B, int H, int T,
                         int n_keys, int nsplit, float *out);
 

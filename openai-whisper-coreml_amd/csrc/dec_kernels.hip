@@ -2,19 +2,22 @@
 // K10-K14): batch-of-B single-token decoder pass with a KV cache.
 //
 // Regime: B <= 16 sequences, so every matrix product is a "skinny" GEMM that streams each
-// weight exactly once -- HBM-bound.  Design for CDNA4:
+// weight exactly once -- HBM-bound, and at Whisper's sizes latency-bound per launch.  Design:
 //   * dec_gemv: one workgroup per 16 output features; its NW waves split K; every lane
-//     issues all of its 16-byte weight loads (up to 10 per lane = 10 KiB per wave in
-//     flight) BEFORE touching the activations, straight into VGPRs (no LDS round trip for
-//     data that is used once).  The product itself runs on the matrix pipe:
-//     v_mfma_f32_16x16x32_bf16 with the batch padded to 16 rows -- the weight fragment a
-//     lane loaded (8 consecutive k of one output row) IS the B operand, no shuffle.
-//     LayerNorm, the attention-partial combine, bias, GELU, residual add, KV-cache append
-//     and the logits arg-max are fused into the prologue / epilogue, so a decoder layer is
-//     8 launches.
-//   * dec_attention: single-query attention over the bf16 K/V cache, 8 lanes per 128-byte
-//     row (coalesced), fp32 softmax, flash-decoding split over the 1500 encoder frames so
-//     all 256 CUs stream; partial (m, l, o) triples are combined by the consumer GEMV.
+//     issues all of its 16-byte weight loads (10 per lane = 10 KiB per wave in flight)
+//     BEFORE touching the activations, straight into VGPRs (no LDS round trip for data that
+//     is used once, non-temporal so the stream does not evict the KV cache from L2/MALL).
+//     The product runs on the matrix pipe: v_mfma_f32_16x16x32_bf16 with the batch padded
+//     to 16 rows -- the weight fragment a lane loaded (8 consecutive k of one output row)
+//     IS the B operand, no shuffle.  LayerNorm (two-pass fp32 statistics, rows split over the
+//     waves along K, normalised tile kept in wave-private LDS), bias, GELU, residual add,
+//     KV-cache append and the logits arg-max are fused in, so a decoder layer is 8 launches.
+//   * dec_attention: single-query attention over the bf16 K/V cache; 16 waves per (sequence,
+//     head), 8 lanes per 128-byte row, 4 loads per lane in flight; fp32 softmax; writes the
+//     bf16 head output the out-projection consumes.  Optional flash-decoding split over the
+//     keys (small batches) with a combine kernel.
+//   * the decode position lives in HBM (*pos_ptr) and is advanced by the arg-max kernel, so
+//     ONE captured hipGraph of the whole step replays for every position.
 #include "model.h"
 
 namespace {
@@ -47,140 +50,177 @@ struct DecGemvDev {
     const float *bias;
     const float *x, *ln_g, *ln_b;
     const bf16_t *a_bf16;
-    const float *part;
-    int nsplit;
     float *out_f32;
     bf16_t *out_bf16;
     bf16_t *kcache, *vcache;
-    int pos, n_ctx, n_head;
+    const int *pos_ptr;  // decode position lives in HBM so a captured hipGraph replays unchanged
+    int n_ctx, n_head;
     long ldo;
     unsigned long long *tilemax;  // [B][n_tiles] (DE_LOGITS)
     int n_tiles;
     int arg_first, arg_last;
 };
 
-
-// One group of G k-steps: issue all G weight loads (16 B per lane each, non-temporal: every
-// weight byte is used once per step), then build the A fragments and run the MFMAs.
+// G k-steps: all G weight loads (16 B per lane each) are issued before the first MFMA.
+// A fragments come either from the wave-private LDS image built by the LayerNorm prologue
+// or straight from a bf16 activation row in L2 -- always UNCONDITIONAL loads from a clamped
+// row (a lane-divergent branch around a load makes hipcc serialise it behind
+// s_waitcnt vmcnt(0): 10 dependent L2 round trips per wave, measured ~10 us per launch).
 template <int AMODE, int G>
-__device__ __forceinline__ void gemv_group(const DecGemvDev &p, const bf16_t *wp, int s0, int kbase, int kq,
-                                           int nrow, bool live, float mean, float rstd, f32x4 &acc) {
-    u32x4 wf[G];
+__device__ __forceinline__ void gemv_group(const bf16_t *wp, int s0, const char *xs_row, const bf16_t *a_row,
+                                           int kq, bool live, f32x4 &acc) {
+    u32x4 wf[G], af[G];
 #pragma unroll
     for (int u = 0; u < G; ++u) wf[u] = __builtin_nontemporal_load((const u32x4 *)(wp + (s0 + u) * 32));
 #pragma unroll
     for (int u = 0; u < G; ++u) {
-        const int k = kbase + (s0 + u) * 32 + kq * 8;
-        uint4 av = make_uint4(0, 0, 0, 0);
-        if (live) {
-            if (AMODE == DA_BF16) {
-                av = *(const uint4 *)(p.a_bf16 + (long)nrow * p.K + k);
-            } else if (AMODE == DA_LN) {
-                const float4 x0 = *(const float4 *)(p.x + (long)nrow * p.K + k);
-                const float4 x1 = *(const float4 *)(p.x + (long)nrow * p.K + k + 4);
-                const float4 g0 = *(const float4 *)(p.ln_g + k), g1 = *(const float4 *)(p.ln_g + k + 4);
-                const float4 b0 = *(const float4 *)(p.ln_b + k), b1 = *(const float4 *)(p.ln_b + k + 4);
-                av.x = pack2((x0.x - mean) * rstd * g0.x + b0.x, (x0.y - mean) * rstd * g0.y + b0.y);
-                av.y = pack2((x0.z - mean) * rstd * g0.z + b0.z, (x0.w - mean) * rstd * g0.w + b0.w);
-                av.z = pack2((x1.x - mean) * rstd * g1.x + b1.x, (x1.y - mean) * rstd * g1.y + b1.y);
-                av.w = pack2((x1.z - mean) * rstd * g1.z + b1.z, (x1.w - mean) * rstd * g1.w + b1.w);
-            } else {  // DA_ATTN: combine flash-decoding partials (m, l, o[64]) of head k/64
-                const int h = k >> 6, e = k & 63;
-                const float *pp = p.part + ((long)(nrow * p.n_head + h) * p.nsplit) * 66;
-                float M = -1e30f;
-                for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, pp[s * 66]);
-                float den = 0.f, num[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int s = 0; s < p.nsplit; ++s) {
-                    const float w = __expf(pp[s * 66] - M);
-                    den += w * pp[s * 66 + 1];
+        if (AMODE == DA_LN)
+            af[u] = *(const u32x4 *)(xs_row + ((s0 + u) * 32 + kq * 8) * 2);
+        else
+            af[u] = *(const u32x4 *)(a_row + (s0 + u) * 32 + kq * 8);
+    }
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) num[i] += w * pp[s * 66 + 2 + e + i];
-                }
-                const float inv = 1.0f / den;
-                av.x = pack2(num[0] * inv, num[1] * inv);
-                av.y = pack2(num[2] * inv, num[3] * inv);
-                av.z = pack2(num[4] * inv, num[5] * inv);
-                av.w = pack2(num[6] * inv, num[7] * inv);
-            }
-        }
+    for (int u = 0; u < G; ++u) {
+        u32x4 av = af[u];
+        if (!live) av = (u32x4){0u, 0u, 0u, 0u};
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av),
                                                       __builtin_bit_cast(bf16x8, wf[u]), acc, 0, 0, 0);
     }
 }
 
-template <int AMODE, int EPI, int NW>
+// LDS carve (dynamic): red [NW][64][4] f32 | part [2][NW][16] f32 | xs [NW][B][KC+8] bf16 (DA_LN)
+template <int AMODE, int EPI, int NW, int BMAX>
 __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
-    __shared__ float stats[WM_DEC_MAXB][2];
-    __shared__ float red[NW][64][4];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *red = (float *)smem;
+    float *part = red + NW * 256;
+    char *xs_all = (char *)(part + 2 * NW * 16);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrow = lane & 15, kq = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int kbase = wave * p.KC;
     const int nsteps = p.KC >> 5;
     const bf16_t *wp = p.W + (long)(n0 + nrow) * p.K + kbase + kq * 8;
+    const bool live = nrow < p.B;
+    const int rowc = live ? nrow : p.B - 1;  // clamped batch row for unconditional loads
+    const int xs_stride = (p.KC + 8) * 2;    // bytes; the 16 B pad keeps ds_read_b128 conflict-free
+    char *xs = xs_all + (long)wave * p.B * xs_stride;
 
-    // ---- LayerNorm statistics (fp32, eps 1e-5) for the B live rows ------------------------
     if (AMODE == DA_LN) {
-        for (int b = wave; b < p.B; b += NW) {
-            const float *xr = p.x + (long)b * p.K;
+        // ---- fused LayerNorm: this wave normalises x[0..B)[kbase .. kbase+KC) ---------------
+        // lane owns float4 columns j4 = lane + 64*u; two-pass fp32 statistics across the
+        // workgroup (a row is split over the NW waves along K).
+        const int kc4 = p.KC >> 2;
+        constexpr int UMAX = 3;
+        float4 xv[BMAX][UMAX];
+        int j4c[UMAX];
+        bool jv[UMAX];
+#pragma unroll
+        for (int u = 0; u < UMAX; ++u) {
+            const int j4 = lane + 64 * u;
+            jv[u] = j4 < kc4;
+            j4c[u] = jv[u] ? j4 : kc4 - 1;
+        }
+#pragma unroll
+        for (int b = 0; b < BMAX; ++b) {
+            const int bc = b < p.B ? b : p.B - 1;
+#pragma unroll
+            for (int u = 0; u < UMAX; ++u)
+                xv[b][u] = *(const float4 *)(p.x + (long)bc * p.K + kbase + 4 * j4c[u]);
+        }
+        float4 gv[UMAX], bv[UMAX];
+#pragma unroll
+        for (int u = 0; u < UMAX; ++u) {
+            gv[u] = *(const float4 *)(p.ln_g + kbase + 4 * j4c[u]);
+            bv[u] = *(const float4 *)(p.ln_b + kbase + 4 * j4c[u]);
+        }
+        // pass 1: row sums
+#pragma unroll
+        for (int b = 0; b < BMAX; ++b) {
             float s = 0.f;
-            for (int k = lane * 4; k < p.K; k += 256) {
-                const float4 v = *(const float4 *)(xr + k);
-                s += (v.x + v.y) + (v.z + v.w);
-            }
+#pragma unroll
+            for (int u = 0; u < UMAX; ++u)
+                if (jv[u]) s += (xv[b][u].x + xv[b][u].y) + (xv[b][u].z + xv[b][u].w);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            const float mean = s / (float)p.K;
+            if (lane == 0) part[wave * 16 + b] = s;
+        }
+        __syncthreads();
+        float mean[BMAX];
+#pragma unroll
+        for (int b = 0; b < BMAX; ++b) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += part[w * 16 + b];
+            mean[b] = s / (float)p.K;
+        }
+        // pass 2: centred second moment
+#pragma unroll
+        for (int b = 0; b < BMAX; ++b) {
             float q = 0.f;
-            for (int k = lane * 4; k < p.K; k += 256) {
-                const float4 v = *(const float4 *)(xr + k);
-                const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
-                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-            }
+#pragma unroll
+            for (int u = 0; u < UMAX; ++u)
+                if (jv[u]) {
+                    const float a0 = xv[b][u].x - mean[b], a1 = xv[b][u].y - mean[b];
+                    const float a2 = xv[b][u].z - mean[b], a3 = xv[b][u].w - mean[b];
+                    q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-            if (lane == 0) {
-                stats[b][0] = mean;
-                stats[b][1] = rsqrtf(q / (float)p.K + 1e-5f);
+            if (lane == 0) part[NW * 16 + wave * 16 + b] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < BMAX; ++b) {
+            if (b < p.B) {  // wave-uniform
+                float q = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) q += part[NW * 16 + w * 16 + b];
+                const float rstd = rsqrtf(q / (float)p.K + 1e-5f);
+#pragma unroll
+                for (int u = 0; u < UMAX; ++u)
+                    if (jv[u]) {
+                        const unsigned lo = pack2((xv[b][u].x - mean[b]) * rstd * gv[u].x + bv[u].x,
+                                                  (xv[b][u].y - mean[b]) * rstd * gv[u].y + bv[u].y);
+                        const unsigned hi = pack2((xv[b][u].z - mean[b]) * rstd * gv[u].z + bv[u].z,
+                                                  (xv[b][u].w - mean[b]) * rstd * gv[u].w + bv[u].w);
+                        *(uint2 *)(xs + b * xs_stride + (lane + 64 * u) * 8) = make_uint2(lo, hi);
+                    }
             }
         }
         __syncthreads();
     }
 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const bool live = nrow < p.B;  // A row = batch index
-    float mean = 0.f, rstd = 0.f;
-    if (AMODE == DA_LN && live) {
-        mean = stats[nrow][0];
-        rstd = stats[nrow][1];
-    }
-
+    const char *xs_row = xs + rowc * xs_stride;
+    const bf16_t *a_row = (AMODE == DA_BF16) ? p.a_bf16 + (long)rowc * p.K + kbase : nullptr;
     int s0 = 0;
+    if (nsteps % 12 == 0)
+        for (; s0 + 12 <= nsteps; s0 += 12) gemv_group<AMODE, 12>(wp, s0, xs_row, a_row, kq, live, acc);
     if (nsteps % 10 == 0)
-        for (; s0 + 10 <= nsteps; s0 += 10) gemv_group<AMODE, 10>(p, wp, s0, kbase, kq, nrow, live, mean, rstd, acc);
-    for (; s0 + 4 <= nsteps; s0 += 4) gemv_group<AMODE, 4>(p, wp, s0, kbase, kq, nrow, live, mean, rstd, acc);
-    for (; s0 < nsteps; ++s0) gemv_group<AMODE, 1>(p, wp, s0, kbase, kq, nrow, live, mean, rstd, acc);
+        for (; s0 + 10 <= nsteps; s0 += 10) gemv_group<AMODE, 10>(wp, s0, xs_row, a_row, kq, live, acc);
+    for (; s0 + 8 <= nsteps; s0 += 8) gemv_group<AMODE, 8>(wp, s0, xs_row, a_row, kq, live, acc);
+    for (; s0 + 2 <= nsteps; s0 += 2) gemv_group<AMODE, 2>(wp, s0, xs_row, a_row, kq, live, acc);
+    for (; s0 < nsteps; ++s0) gemv_group<AMODE, 1>(wp, s0, xs_row, a_row, kq, live, acc);
 
     // ---- cross-wave (split-K) reduction through LDS ----------------------------------------
     if (NW > 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][lane][r] = acc[r];
+        *(f32x4 *)(red + (wave * 64 + lane) * 4) = acc;
         __syncthreads();
         if (wave != 0) return;
 #pragma unroll
-        for (int w = 1; w < NW; ++w)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] += red[w][lane][r];
+        for (int w = 1; w < NW; ++w) acc += *(const f32x4 *)(red + (w * 64 + lane) * 4);
     }
 
     // ---- epilogue (wave 0): D col n = lane & 15, rows b = kq*4 + r --------------------------
     const int n = n0 + nrow;
     const bool nvalid = n < p.N;
-    const float bv = (nvalid && p.bias) ? p.bias[n] : 0.f;
+    const float bvs = (nvalid && p.bias) ? p.bias[n] : 0.f;
+    const int pos = p.pos_ptr ? *p.pos_ptr : 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int b = kq * 4 + r;
-        const float v = acc[r] + bv;
+        const float v = acc[r] + bvs;
         if (EPI == DE_LOGITS) {
             // arg-max over [arg_first, arg_last], first maximal index wins (Whisper.swift:38)
             unsigned long long key = 0ull;
@@ -202,7 +242,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
             } else {
                 const int hn = (n < 2 * d) ? n - d : n - 2 * d;
                 bf16_t *c = (n < 2 * d) ? p.kcache : p.vcache;
-                c[((long)(b * p.n_head + (hn >> 6)) * p.n_ctx + p.pos) * 64 + (hn & 63)] = f2bf(v);
+                c[((long)(b * p.n_head + (hn >> 6)) * p.n_ctx + pos) * 64 + (hn & 63)] = f2bf(v);
             }
         } else if (EPI == DE_Q) {
             p.out_f32[(long)b * p.ldo + n] = v;
@@ -215,37 +255,48 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
 }
 
 // ------------------------------------------------------------------ token embedding ------
-__global__ __launch_bounds__(256) void dec_embed_kernel(const int *__restrict__ tokens, int pos,
-                                                        const bf16_t *__restrict__ emb,
+// x[b] = token_embedding[seq[pos][b]] + positional_embedding[pos]
+__global__ __launch_bounds__(256) void dec_embed_kernel(const int *__restrict__ seq, const int *__restrict__ pos_ptr,
+                                                        int B, const bf16_t *__restrict__ emb,
                                                         const float *__restrict__ pemb, int d,
                                                         float *__restrict__ x) {
     const int b = blockIdx.x;
-    const long tok = tokens[b];
+    const int pos = *pos_ptr;
+    const long tok = seq[pos * B + b];
     for (int j = threadIdx.x; j < d; j += 256)
         x[(long)b * d + j] = bf2f(emb[tok * d + j]) + pemb[(long)pos * d + j];
 }
 
 // ------------------------------------------------------------------ single-query attention
-// grid (B*H, nsplit); 256 threads.  Keys [start, end) of this split; 8 lanes share a
-// 128-byte K/V row (16 B each), 8 rows per wave-load.
-__global__ __launch_bounds__(256) void dec_attn_kernel(const float *__restrict__ q,
-                                                       const bf16_t *__restrict__ kc,
-                                                       const bf16_t *__restrict__ vc, int H, int d,
-                                                       int T_stride, int n_keys, int nsplit,
-                                                       float *__restrict__ part) {
-    __shared__ float sc[512];
-    __shared__ float wred[4];
-    __shared__ float wacc[4][64];
+// grid (B*H, nsplit), 1024 threads = 16 waves.  Keys [start, end) of this split; 8 lanes share
+// one 128-byte K/V row (16 B each), a wave covers 8 rows per load, the 16 waves 128 rows; every
+// lane keeps ATT_UNR loads in flight (16 waves x 4 KiB = 64 KiB per CU) so a CU streams its
+// (sequence, head) cache slice at HBM rate.  nsplit == 1: writes the normalised head output
+// as bf16 (the out-projection's A operand); nsplit > 1: writes (m, l, o[64]) partials for
+// dec_attn_combine_kernel.
+constexpr int ATT_UNR = 4;
+constexpr int ATT_NW = 16;
+constexpr int ATT_MAXK = 1536;
+
+__global__ __launch_bounds__(1024) void dec_attn_kernel(const float *__restrict__ q,
+                                                        const bf16_t *__restrict__ kc,
+                                                        const bf16_t *__restrict__ vc, int H, int d,
+                                                        int T_stride, int n_keys_const,
+                                                        const int *__restrict__ pos_ptr, int nsplit,
+                                                        float *__restrict__ part, bf16_t *__restrict__ att) {
+    __shared__ float sc[ATT_MAXK];
+    __shared__ float wred[ATT_NW];
+    __shared__ float wacc[ATT_NW][64];
     const int bh = blockIdx.x, b = bh / H, h = bh % H, sp = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rg = lane >> 3, e8 = lane & 7;
+    const int n_keys = pos_ptr ? (*pos_ptr + 1) : n_keys_const;
     int chunk = (n_keys + nsplit - 1) / nsplit;
     chunk = (chunk + 7) & ~7;
     const int start = sp * chunk;
     int end = start + chunk;
     if (end > n_keys) end = n_keys;
     const int cnt = end > start ? end - start : 0;
-    float *po = part + ((long)bh * nsplit + sp) * 66;
 
     float qe[8];
     {
@@ -253,42 +304,49 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float *__restrict__
 #pragma unroll
         for (int i = 0; i < 8; ++i) qe[i] = qp[i] * 0.125f;  // hd^-0.5 (== hd^-0.25 on q and on k)
     }
-    const bf16_t *kb = kc + (long)bh * T_stride * 64 + e8 * 8;
-    const bf16_t *vb = vc + (long)bh * T_stride * 64 + e8 * 8;
+    const bf16_t *kb = kc + ((long)bh * T_stride + start) * 64 + e8 * 8;
+    const bf16_t *vb = vc + ((long)bh * T_stride + start) * 64 + e8 * 8;
+    const int last = cnt > 0 ? cnt - 1 : 0;
 
     // ---- scores ---------------------------------------------------------------------------
     float mloc = -1e30f;
-    for (int i0 = wave * 8; i0 < cnt; i0 += 32) {
-        const int i = i0 + rg;
-        float s = -1e30f;
-        if (i < cnt) {
-            const uint4 kv = *(const uint4 *)(kb + (long)(start + i) * 64);
-            const unsigned w[4] = {kv.x, kv.y, kv.z, kv.w};
+    for (int i0 = wave * 8; i0 < cnt; i0 += ATT_NW * 8 * ATT_UNR) {
+        u32x4 kv[ATT_UNR];
+#pragma unroll
+        for (int u = 0; u < ATT_UNR; ++u) {
+            int i = i0 + u * ATT_NW * 8 + rg;
+            i = i < cnt ? i : last;  // clamped: unconditional load
+            kv[u] = *(const u32x4 *)(kb + (long)i * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < ATT_UNR; ++u) {
+            const int i = i0 + u * ATT_NW * 8 + rg;
             float a = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                a += qe[2 * j] * __uint_as_float(w[j] << 16);
-                a += qe[2 * j + 1] * __uint_as_float(w[j] & 0xffff0000u);
+                a += qe[2 * j] * __uint_as_float(kv[u][j] << 16);
+                a += qe[2 * j + 1] * __uint_as_float(kv[u][j] & 0xffff0000u);
             }
-            s = a;
-        }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        if (i < cnt) {
-            if (e8 == 0) sc[i] = s;
-            mloc = fmaxf(mloc, s);
+            a += __shfl_xor(a, 1);
+            a += __shfl_xor(a, 2);
+            a += __shfl_xor(a, 4);
+            if (i < cnt) {
+                if (e8 == 0) sc[i] = a;
+                mloc = fmaxf(mloc, a);
+            }
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, o));
     if (lane == 0) wred[wave] = mloc;
     __syncthreads();
-    const float M = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    float M = wred[0];
+#pragma unroll
+    for (int w = 1; w < ATT_NW; ++w) M = fmaxf(M, wred[w]);
     __syncthreads();
     // ---- exp + sum ------------------------------------------------------------------------
     float lloc = 0.f;
-    for (int i = tid; i < cnt; i += 256) {
+    for (int i = tid; i < cnt; i += ATT_NW * 64) {
         const float pv = __expf(sc[i] - M);
         sc[i] = pv;
         lloc += pv;
@@ -297,19 +355,27 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float *__restrict__
     for (int o = 32; o > 0; o >>= 1) lloc += __shfl_xor(lloc, o);
     if (lane == 0) wred[wave] = lloc;
     __syncthreads();
-    const float L = (wred[0] + wred[1]) + (wred[2] + wred[3]);
+    float L = 0.f;
+#pragma unroll
+    for (int w = 0; w < ATT_NW; ++w) L += wred[w];
     // ---- o = sum_i p_i V[i] -----------------------------------------------------------------
     float oa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i0 = wave * 8; i0 < cnt; i0 += 32) {
-        const int i = i0 + rg;
-        if (i < cnt) {
-            const float pv = sc[i];
-            const uint4 vv = *(const uint4 *)(vb + (long)(start + i) * 64);
-            const unsigned w[4] = {vv.x, vv.y, vv.z, vv.w};
+    for (int i0 = wave * 8; i0 < cnt; i0 += ATT_NW * 8 * ATT_UNR) {
+        u32x4 vv[ATT_UNR];
+#pragma unroll
+        for (int u = 0; u < ATT_UNR; ++u) {
+            int i = i0 + u * ATT_NW * 8 + rg;
+            i = i < cnt ? i : last;
+            vv[u] = *(const u32x4 *)(vb + (long)i * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < ATT_UNR; ++u) {
+            const int i = i0 + u * ATT_NW * 8 + rg;
+            const float pv = i < cnt ? sc[i] : 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                oa[2 * j] += pv * __uint_as_float(w[j] << 16);
-                oa[2 * j + 1] += pv * __uint_as_float(w[j] & 0xffff0000u);
+                oa[2 * j] += pv * __uint_as_float(vv[u][j] << 16);
+                oa[2 * j + 1] += pv * __uint_as_float(vv[u][j] & 0xffff0000u);
             }
         }
     }
@@ -324,40 +390,71 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const float *__restrict__
         for (int i = 0; i < 8; ++i) wacc[wave][e8 * 8 + i] = oa[i];
     }
     __syncthreads();
-    if (tid < 64) po[2 + tid] = (wacc[0][tid] + wacc[1][tid]) + (wacc[2][tid] + wacc[3][tid]);
-    if (tid == 0) {
-        po[0] = cnt > 0 ? M : -1e30f;
-        po[1] = cnt > 0 ? L : 0.f;
+    if (tid < 64) {
+        float o = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATT_NW; ++w) o += wacc[w][tid];
+        if (nsplit == 1) {
+            att[(long)b * d + h * 64 + tid] = f2bf(o / L);
+        } else {
+            float *po = part + ((long)bh * nsplit + sp) * 66;
+            po[2 + tid] = o;
+            if (tid == 0) {
+                po[0] = cnt > 0 ? M : -1e30f;
+                po[1] = cnt > 0 ? L : 0.f;
+            }
+        }
     }
 }
 
+// Combine flash-decoding partials -> bf16 head outputs.  grid B*H, 64 threads.
+__global__ __launch_bounds__(64) void dec_attn_combine_kernel(const float *__restrict__ part, int nsplit, int H,
+                                                              int d, bf16_t *__restrict__ att) {
+    const int bh = blockIdx.x, b = bh / H, h = bh % H, e = threadIdx.x;
+    const float *pp = part + (long)bh * nsplit * 66;
+    float M = -1e30f;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pp[s * 66]);
+    float den = 0.f, num = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float w = __expf(pp[s * 66] - M);
+        den += w * pp[s * 66 + 1];
+        num += w * pp[s * 66 + 2 + e];
+    }
+    att[(long)b * d + h * 64 + e] = f2bf(num / den);
+}
+
 // ------------------------------------------------------------------ arg-max -> next token
+// ONE workgroup: reduces the per-tile packed maxima of all B rows, writes the chosen token of
+// row b into the sequence buffer at position pos+1 (when that position is not part of the
+// prompt) and finally advances the device-side position -- the only writer of *pos_ptr.
 __global__ __launch_bounds__(256) void argmax_tokens_kernel(const unsigned long long *__restrict__ tilemax,
-                                                            int n_tiles, int *__restrict__ cur,
-                                                            int *__restrict__ history, int hist_stride,
-                                                            int hist_pos, int *__restrict__ result,
-                                                            int arg_first) {
+                                                            int n_tiles, int B, int *__restrict__ seq,
+                                                            int *__restrict__ pos_ptr, int n_prompt,
+                                                            int *__restrict__ result, int arg_first) {
     __shared__ unsigned long long wk[4];
-    const int b = blockIdx.x;
-    unsigned long long key = 0ull;
-    for (int t = threadIdx.x; t < n_tiles; t += 256) {
-        const unsigned long long k = tilemax[(long)b * n_tiles + t];
-        key = k > key ? k : key;
-    }
+    const int pos = pos_ptr ? *pos_ptr : 0;
+    for (int b = 0; b < B; ++b) {
+        unsigned long long key = 0ull;
+        for (int t = threadIdx.x; t < n_tiles; t += 256) {
+            const unsigned long long k = tilemax[(long)b * n_tiles + t];
+            key = k > key ? k : key;
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long ok = __shfl_xor(key, o);
-        key = ok > key ? ok : key;
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long ok = __shfl_xor(key, o);
+            key = ok > key ? ok : key;
+        }
+        if ((threadIdx.x & 63) == 0) wk[threadIdx.x >> 6] = key;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) key = wk[w] > key ? wk[w] : key;
+            const int tok = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+            if (seq && pos + 1 >= n_prompt) seq[(pos + 1) * B + b] = tok;
+            if (result) result[b] = tok - arg_first;
+        }
+        __syncthreads();
     }
-    if ((threadIdx.x & 63) == 0) wk[threadIdx.x >> 6] = key;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) key = wk[w] > key ? wk[w] : key;
-        const int tok = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
-        if (cur) cur[b] = tok;
-        if (history) history[(long)b * hist_stride + hist_pos] = tok;
-        if (result) result[b] = tok - arg_first;
-    }
+    if (threadIdx.x == 0 && pos_ptr) *pos_ptr = pos + 1;
 }
 
 // ------------------------------------------------------------------ synthetic weights ----
@@ -399,38 +496,51 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(void *dst, int is_bf16,
     }
 }
 
-template <int AMODE, int EPI>
+template <int AMODE, int EPI, int BMAX>
 int launch_gemv(wm_ctx *ctx, const DecGemvDev &p, int nw, int grid) {
     hipStream_t s = ctx->stream;
+    size_t lds = (size_t)nw * 1024 + 2 * nw * 16 * 4;
+    if (AMODE == DA_LN) lds += (size_t)nw * p.B * (p.KC + 8) * 2;
+    lds = (lds + 15) & ~(size_t)15;
     switch (nw) {
-        case 1: dec_gemv_kernel<AMODE, EPI, 1><<<grid, 64, 0, s>>>(p); break;
-        case 2: dec_gemv_kernel<AMODE, EPI, 2><<<grid, 128, 0, s>>>(p); break;
-        case 4: dec_gemv_kernel<AMODE, EPI, 4><<<grid, 256, 0, s>>>(p); break;
-        case 8: dec_gemv_kernel<AMODE, EPI, 8><<<grid, 512, 0, s>>>(p); break;
-        case 16: dec_gemv_kernel<AMODE, EPI, 16><<<grid, 1024, 0, s>>>(p); break;
+        case 1: dec_gemv_kernel<AMODE, EPI, 1, BMAX><<<grid, 64, lds, s>>>(p); break;
+        case 2: dec_gemv_kernel<AMODE, EPI, 2, BMAX><<<grid, 128, lds, s>>>(p); break;
+        case 4: dec_gemv_kernel<AMODE, EPI, 4, BMAX><<<grid, 256, lds, s>>>(p); break;
+        case 8: dec_gemv_kernel<AMODE, EPI, 8, BMAX><<<grid, 512, lds, s>>>(p); break;
+        case 16: dec_gemv_kernel<AMODE, EPI, 16, BMAX><<<grid, 1024, lds, s>>>(p); break;
         default: wm_set_error("dec_gemv: bad wave count %d", nw); return WM_ERR_INVALID;
     }
     WM_HIP(hipGetLastError());
     return WM_OK;
 }
 
+template <int AMODE, int EPI>
+int launch_gemv_b(wm_ctx *ctx, const DecGemvDev &p, int nw, int grid) {
+    if (AMODE == DA_LN && p.B > 8) return launch_gemv<AMODE, EPI, 16>(ctx, p, nw, grid);
+    return launch_gemv<AMODE, EPI, 8>(ctx, p, nw, grid);
+}
+
 }  // namespace
 
-static int pick_waves(int K) {
+static int pick_waves(int K, bool ln) {
     int nw = 16;
     while (nw > 1 && (K / 256 < nw || K % (32 * nw) != 0)) nw >>= 1;
+    // the LayerNorm prologue holds KC/4 float4 columns in at most 3 x 64 lanes: KC <= 768
+    while (ln && K / nw > 768 && nw < 16) nw <<= 1;
     return nw;
 }
 
 int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     WM_REQUIRE(a.B >= 1 && a.B <= WM_DEC_MAXB, WM_ERR_INVALID, "dec_gemv: B=%d out of range", a.B);
     WM_REQUIRE(a.K % 32 == 0, WM_ERR_INVALID, "dec_gemv: K=%d must be a multiple of 32", a.K);
-    const int nw = pick_waves(a.K);
+    const int nw = pick_waves(a.K, a.a_mode == DA_LN);
+    WM_REQUIRE(a.K % (32 * nw) == 0 && (a.a_mode != DA_LN || a.K / nw <= 768), WM_ERR_INVALID,
+               "dec_gemv: K=%d cannot be split over %d waves", a.K, nw);
     DecGemvDev p;
     p.B = a.B; p.N = a.N; p.K = a.K; p.KC = a.K / nw;
     p.W = a.W; p.bias = a.bias; p.x = a.x; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.a_bf16 = a.a_bf16;
-    p.part = a.part; p.nsplit = a.nsplit; p.out_f32 = a.out_f32; p.out_bf16 = a.out_bf16;
-    p.kcache = a.kcache; p.vcache = a.vcache; p.pos = a.pos; p.n_ctx = a.n_ctx; p.n_head = a.n_head;
+    p.out_f32 = a.out_f32; p.out_bf16 = a.out_bf16;
+    p.kcache = a.kcache; p.vcache = a.vcache; p.pos_ptr = a.pos_ptr; p.n_ctx = a.n_ctx; p.n_head = a.n_head;
     p.ldo = a.ldo; p.tilemax = a.argmax; p.arg_first = a.arg_first; p.arg_last = a.arg_last;
     const int grid = (a.N + 15) / 16;
     p.n_tiles = grid;
@@ -438,31 +548,27 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     switch (key) {
         case DA_LN * 8 + DE_QKV: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_qkv", ctx->stream);
-            return launch_gemv<DA_LN, DE_QKV>(ctx, p, nw, grid);
+            return launch_gemv_b<DA_LN, DE_QKV>(ctx, p, nw, grid);
         }
         case DA_LN * 8 + DE_Q: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_q", ctx->stream);
-            return launch_gemv<DA_LN, DE_Q>(ctx, p, nw, grid);
+            return launch_gemv_b<DA_LN, DE_Q>(ctx, p, nw, grid);
         }
         case DA_LN * 8 + DE_GELU: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_fc1", ctx->stream);
-            return launch_gemv<DA_LN, DE_GELU>(ctx, p, nw, grid);
+            return launch_gemv_b<DA_LN, DE_GELU>(ctx, p, nw, grid);
         }
         case DA_LN * 8 + DE_LOGITS: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_logits", ctx->stream);
-            return launch_gemv<DA_LN, DE_LOGITS>(ctx, p, nw, grid);
-        }
-        case DA_ATTN * 8 + DE_RESID: {
-            WmProfScope ps(&ctx->prof, "dec_gemv_attn_out", ctx->stream);
-            return launch_gemv<DA_ATTN, DE_RESID>(ctx, p, nw, grid);
+            return launch_gemv_b<DA_LN, DE_LOGITS>(ctx, p, nw, grid);
         }
         case DA_BF16 * 8 + DE_RESID: {
-            WmProfScope ps(&ctx->prof, "dec_gemv_fc2", ctx->stream);
-            return launch_gemv<DA_BF16, DE_RESID>(ctx, p, nw, grid);
+            WmProfScope ps(&ctx->prof, a.K > a.N ? "dec_gemv_fc2" : "dec_gemv_attn_out", ctx->stream);
+            return launch_gemv_b<DA_BF16, DE_RESID>(ctx, p, nw, grid);
         }
         case DA_BF16 * 8 + DE_Q: {
             WmProfScope ps(&ctx->prof, "dec_gemv_plain", ctx->stream);
-            return launch_gemv<DA_BF16, DE_Q>(ctx, p, nw, grid);
+            return launch_gemv_b<DA_BF16, DE_Q>(ctx, p, nw, grid);
         }
         default:
             wm_set_error("dec_gemv: unsupported mode pair (%d, %d)", a.a_mode, a.epi);
@@ -470,30 +576,46 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     }
 }
 
-int wm_dec_embed(wm_ctx *ctx, const int *tokens, int B, int pos, const bf16_t *emb, const float *pemb,
-                 int d, float *x, unsigned long long *) {
+int wm_dec_embed(wm_ctx *ctx, const int *seq, const int *pos_ptr, int B, const bf16_t *emb, const float *pemb,
+                 int d, float *x) {
     WmProfScope ps(&ctx->prof, "dec_embed", ctx->stream);
-    dec_embed_kernel<<<B, 256, 0, ctx->stream>>>(tokens, pos, emb, pemb, d, x);
+    dec_embed_kernel<<<B, 256, 0, ctx->stream>>>(seq, pos_ptr, B, emb, pemb, d, x);
     WM_HIP(hipGetLastError());
     return WM_OK;
+}
+
+int wm_dec_attn_splits(int B, int H) {
+    const int bh = B * H;
+    if (bh >= 96) return 1;
+    int ns = (192 + bh - 1) / bh;
+    return ns > 8 ? 8 : ns;
 }
 
 int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
-                     int T_stride, int n_keys, int nsplit, float *part) {
-    WM_REQUIRE(n_keys >= 1 && (n_keys + nsplit - 1) / nsplit + 8 <= 512, WM_ERR_INVALID,
-               "dec_attention: %d keys / %d splits exceeds the 512-key LDS tile", n_keys, nsplit);
-    WmProfScope ps(&ctx->prof, nsplit > 1 ? "dec_attn_cross" : "dec_attn_self", ctx->stream);
-    dim3 grid(B * H, nsplit);
-    dec_attn_kernel<<<grid, 256, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, nsplit, part);
-    WM_HIP(hipGetLastError());
+                     int T_stride, int n_keys, const int *pos_ptr, int nsplit, float *part, bf16_t *att,
+                     bool cross) {
+    WM_REQUIRE(nsplit >= 1 && nsplit <= 8, WM_ERR_INVALID, "dec_attention: nsplit %d out of range", nsplit);
+    WM_REQUIRE(T_stride <= ATT_MAXK && n_keys <= ATT_MAXK, WM_ERR_INVALID,
+               "dec_attention: more than %d keys", ATT_MAXK);
+    {
+        WmProfScope ps(&ctx->prof, cross ? "dec_attn_cross" : "dec_attn_self", ctx->stream);
+        dim3 grid(B * H, nsplit);
+        dec_attn_kernel<<<grid, 1024, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, nsplit,
+                                                       part, att);
+        WM_HIP(hipGetLastError());
+    }
+    if (nsplit > 1) {
+        WmProfScope ps(&ctx->prof, "dec_attn_combine", ctx->stream);
+        dec_attn_combine_kernel<<<B * H, 64, 0, ctx->stream>>>(part, nsplit, H, H * 64, att);
+        WM_HIP(hipGetLastError());
+    }
     return WM_OK;
 }
 
-int wm_argmax_reduce(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *cur,
-                     int *history, int hist_stride, int hist_pos, int *result, int arg_first) {
+int wm_argmax_reduce(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
+                     int n_prompt, int *result, int arg_first) {
     WmProfScope ps(&ctx->prof, "argmax_reduce", ctx->stream);
-    argmax_tokens_kernel<<<B, 256, 0, ctx->stream>>>(tilemax, n_tiles, cur, history, hist_stride, hist_pos,
-                                                     result, arg_first);
+    argmax_tokens_kernel<<<1, 256, 0, ctx->stream>>>(tilemax, n_tiles, B, seq, pos_ptr, n_prompt, result, arg_first);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

@@ -143,13 +143,14 @@ int wm_model_create(wm_ctx *ctx, const wm_dims *dims) {
     // decode-step buffers (batch <= WM_DEC_MAXB)
     WM_TRY(dalloc_t(m, &m->dx, (size_t)WM_DEC_MAXB * d, s));
     WM_TRY(dalloc_t(m, &m->dq, (size_t)WM_DEC_MAXB * d, s));
-    WM_TRY(dalloc_t(m, &m->dpart, (size_t)WM_DEC_MAXB * D.n_text_head * WM_XSPLIT * 66, s));
+    WM_TRY(dalloc_t(m, &m->dpart, (size_t)WM_DEC_MAXB * D.n_text_head * WM_MAXSPLIT * 66, s));
+    WM_TRY(dalloc_t(m, &m->datt, (size_t)WM_DEC_MAXB * d, s));
     WM_TRY(dalloc_t(m, &m->dhid, (size_t)WM_DEC_MAXB * 4 * d, s));
     WM_TRY(dalloc_t(m, &m->dlogits, (size_t)WM_DEC_MAXB * m->vpad, s));
     WM_TRY(dalloc_t(m, &m->dargmax, (size_t)WM_DEC_MAXB * (m->vpad / 16), s));
     WM_TRY(dalloc_t(m, &m->dresult, WM_DEC_MAXB, s));
-    WM_TRY(dalloc_t(m, &m->dtokens, (size_t)WM_DEC_MAXB * D.n_text_ctx, s));
-    WM_TRY(dalloc_t(m, &m->dcur, (size_t)WM_DEC_MAXB * D.n_text_ctx, s));  // [T][B] for teacher forcing
+    WM_TRY(dalloc_t(m, &m->dseq, (size_t)WM_DEC_MAXB * (D.n_text_ctx + 1), s));
+    WM_TRY(dalloc_t(m, &m->dpos, 4, s));
     WM_HIP(hipStreamSynchronize(s));
     return WM_OK;
 }
@@ -157,6 +158,8 @@ int wm_model_create(wm_ctx *ctx, const wm_dims *dims) {
 void wm_model_destroy(wm_ctx *ctx) {
     WmModel *m = ctx->model;
     if (!m) return;
+    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    if (m->graph) (void)hipGraphDestroy(m->graph);
     for (void *p : m->allocs) (void)hipFree(p);
     if (m->pcm_stage) (void)hipFree(m->pcm_stage);
     if (m->io_stage) (void)hipFree(m->io_stage);
@@ -380,13 +383,19 @@ int wm_model_decode_begin(wm_ctx *ctx, int B) {
     return WM_OK;
 }
 
-int wm_model_decode_step(wm_ctx *ctx, int B, int pos, const int *d_tokens, bool want_logits, bool want_argmax,
-                         int arg_first, int arg_last) {
+int wm_model_set_pos(wm_ctx *ctx, int pos) {
+    WmModel *m = ctx->model;
+    WM_HIP(hipMemcpyAsync(m->dpos, &pos, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));  // `pos` is a stack variable
+    return WM_OK;
+}
+
+int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, int arg_last) {
     WmModel *m = ctx->model;
     const wm_dims &D = m->dims;
     const int d = D.n_text_state, H = D.n_text_head, T = D.n_text_ctx, S = 1500;
-    WM_REQUIRE(pos >= 0 && pos < T, WM_ERR_INVALID, "position %d outside the %d-token context", pos, T);
-    WM_TRY(wm_dec_embed(ctx, d_tokens, B, pos, m->tok_emb, m->dec_pos, d, m->dx, nullptr));
+    const int ns = wm_dec_attn_splits(B, H);
+    WM_TRY(wm_dec_embed(ctx, m->dseq, m->dpos, B, m->tok_emb, m->dec_pos, d, m->dx));
     for (int l = 0; l < D.n_text_layer; ++l) {
         const DecLayerW &L = m->dec[l];
         bf16_t *kc = m->skv + (size_t)(l * 2 + 0) * B * H * T * 64;
@@ -398,26 +407,26 @@ int wm_model_decode_step(wm_ctx *ctx, int B, int pos, const int *d_tokens, bool 
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_LN; a.epi = DE_QKV; a.B = B; a.N = 3 * d; a.K = d; a.W = L.wqkv; a.bias = L.bqkv;
         a.x = m->dx; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.out_f32 = m->dq; a.kcache = kc; a.vcache = vc;
-        a.pos = pos; a.n_ctx = T; a.n_head = H;
+        a.pos_ptr = m->dpos; a.n_ctx = T; a.n_head = H;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 2. causal self-attention over positions 0..pos
-        WM_TRY(wm_dec_attention(ctx, m->dq, kc, vc, B, H, T, pos + 1, 1, m->dpart));
+        WM_TRY(wm_dec_attention(ctx, m->dq, kc, vc, B, H, T, 0, m->dpos, ns, m->dpart, m->datt, false));
         // 3. out-projection + residual
         memset(&a, 0, sizeof(a));
-        a.a_mode = DA_ATTN; a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wo; a.bias = L.bo;
-        a.part = m->dpart; a.nsplit = 1; a.n_head = H; a.out_f32 = m->dx; a.ldo = d;
+        a.a_mode = DA_BF16; a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wo; a.bias = L.bo;
+        a.a_bf16 = m->datt; a.out_f32 = m->dx; a.ldo = d;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 4. cross_attn_ln + query projection
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_LN; a.epi = DE_Q; a.B = B; a.N = d; a.K = d; a.W = L.wxq; a.bias = L.bxq;
         a.x = m->dx; a.ln_g = L.lnx_g; a.ln_b = L.lnx_b; a.out_f32 = m->dq; a.ldo = d;
         WM_TRY(wm_dec_gemv(ctx, a));
-        // 5. cross-attention over the 1500 cached encoder frames (flash-decoding splits)
-        WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, WM_XSPLIT, m->dpart));
+        // 5. cross-attention over the 1500 cached encoder frames
+        WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, ns, m->dpart, m->datt, true));
         // 6. out-projection + residual
         memset(&a, 0, sizeof(a));
-        a.a_mode = DA_ATTN; a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wxo; a.bias = L.bxo;
-        a.part = m->dpart; a.nsplit = WM_XSPLIT; a.n_head = H; a.out_f32 = m->dx; a.ldo = d;
+        a.a_mode = DA_BF16; a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wxo; a.bias = L.bxo;
+        a.a_bf16 = m->datt; a.out_f32 = m->dx; a.ldo = d;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 7. mlp_ln + fc1 + GELU
         memset(&a, 0, sizeof(a));
@@ -430,8 +439,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, int pos, const int *d_tokens, bool 
         a.a_bf16 = m->dhid; a.out_f32 = m->dx; a.ldo = d;
         WM_TRY(wm_dec_gemv(ctx, a));
     }
-    if (want_logits || want_argmax) {
-        // final LayerNorm + tied-embedding logits (+ fused arg-max)
+    {   // final LayerNorm + tied-embedding logits + fused per-tile arg-max
         DecGemvArgs a;
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_LN; a.epi = DE_LOGITS; a.B = B; a.N = D.n_vocab; a.K = d; a.W = m->tok_emb;

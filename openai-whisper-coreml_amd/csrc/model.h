@@ -87,13 +87,18 @@ struct WmModel {
     // decode-step buffers
     float *dx = nullptr;        // [16][d]   decoder residual stream
     float *dq = nullptr;        // [16][d]   query (self or cross)
-    float *dpart = nullptr;     // [B][H][NSPLIT_MAX][66] attention partials (m, l, o[64])
+    float *dpart = nullptr;     // [16][H][WM_MAXSPLIT][66] attention partials (m, l, o[64])
+    bf16_t *datt = nullptr;     // [16][d]   attention head outputs (bf16 A operand of the out-projection)
     bf16_t *dhid = nullptr;     // [16][4d]
     float *dlogits = nullptr;   // [B][vpad]
     unsigned long long *dargmax = nullptr;  // [16][vpad/16] per-tile packed (value, ~index) maxima
     int *dresult = nullptr;     // [16] arg-max result relative to arg_first
-    int *dtokens = nullptr;     // [B][n_text_ctx] token history on device
-    int *dcur = nullptr;        // [B] current input token
+    int *dseq = nullptr;        // [n_text_ctx][16->B] token sequence (prompt, then generated), position-major
+    int *dpos = nullptr;        // [1] current decode position (read by every decode kernel)
+    // captured decode step (one hipGraph replayed for every position)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_B = 0, graph_n_prompt = 0, graph_cap_b = 0;
     void *pcm_stage = nullptr;  // host-pointer staging for wm_transcribe_greedy
     size_t pcm_stage_bytes = 0;
     float *io_stage = nullptr;  // staging for host-pointer model calls
@@ -113,11 +118,12 @@ int wm_model_encode_dev(wm_ctx *ctx, const float *d_mel, int B, float *d_xa_out 
 int wm_model_cross_kv(wm_ctx *ctx, int B);                 // from m->xn (bf16 encoder output)
 int wm_model_set_xa(wm_ctx *ctx, const float *d_xa, int B);  // f32 xa -> m->xn (bf16)
 int wm_model_decode_begin(wm_ctx *ctx, int B);
-// One decoder position for all B sequences: input tokens d_tokens[0..B) at position `pos`.
-// want_logits: f32 logits [B][vpad] -> m->dlogits;  want_argmax / want_logits: per-tile
-// packed maxima over [arg_first, arg_last] -> m->dargmax (reduce with wm_argmax_reduce).
-int wm_model_decode_step(wm_ctx *ctx, int B, int pos, const int *d_tokens, bool want_logits, bool want_argmax,
-                         int arg_first, int arg_last);
+// One decoder position for all B sequences: tokens m->dseq[*dpos][0..B), position *m->dpos
+// (device memory).  Always ends with logits -> per-tile arg-max over [arg_first, arg_last]
+// (m->dargmax); want_logits additionally stores f32 logits [B][vpad] in m->dlogits.  Does NOT
+// advance the position: follow with wm_argmax_reduce (which does).
+int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, int arg_last);
+int wm_model_set_pos(wm_ctx *ctx, int pos);
 
 // ---------------------------------------------------------------- kernel launchers ----
 // gemm.hip
@@ -156,8 +162,8 @@ int wm_enc_attention(wm_ctx *ctx, const bf16_t *qk, const bf16_t *vt, bf16_t *at
 
 // dec_kernels.hip
 constexpr int WM_DEC_MAXB = 16;
-constexpr int WM_XSPLIT = 4;  // flash-decoding splits of the 1500-frame cross attention
-enum DecAMode { DA_LN = 0, DA_BF16 = 1, DA_ATTN = 2 };
+constexpr int WM_MAXSPLIT = 8;  // flash-decoding splits of single-query attention (small batches)
+enum DecAMode { DA_LN = 0, DA_BF16 = 1 };
 enum DecEpi { DE_QKV = 0, DE_Q = 1, DE_RESID = 2, DE_GELU = 3, DE_LOGITS = 4 };
 struct DecGemvArgs {
     int a_mode, epi;
@@ -168,25 +174,29 @@ struct DecGemvArgs {
     const float *x;        // DA_LN: residual stream [B][K]
     const float *ln_g, *ln_b;
     const bf16_t *a_bf16;  // DA_BF16: [B][K]
-    const float *part;     // DA_ATTN: partials [B][H][nsplit][66]
-    int nsplit;
     // outputs
     float *out_f32;        // DE_Q: [B][N]; DE_RESID: residual [B][N] (+=); DE_LOGITS: [B][ldo]
     bf16_t *out_bf16;      // DE_GELU: [B][N]
     bf16_t *kcache, *vcache;  // DE_QKV: this layer's [B][H][T][64]
-    int pos, n_ctx, n_head;
+    const int *pos_ptr;       // device-side decode position (DE_QKV appends at *pos_ptr)
+    int n_ctx, n_head;
     long ldo;
     unsigned long long *argmax;  // DE_LOGITS: per-tile packed maxima [B][ceil(N/16)] over [arg_first, arg_last]
     int arg_first, arg_last;
 };
 int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a);
-int wm_dec_embed(wm_ctx *ctx, const int *tokens, int B, int pos, const bf16_t *emb, const float *pemb,
-                 int d, float *x, unsigned long long *argmax_to_clear);
-// Single-query attention over a K/V cache [B][H][T][64]; writes partials (m, l, o[64]).
+// x[b] = token_embedding[seq[*pos_ptr][b]] + positional_embedding[*pos_ptr]
+int wm_dec_embed(wm_ctx *ctx, const int *seq, const int *pos_ptr, int B, const bf16_t *emb, const float *pemb,
+                 int d, float *x);
+// Single-query attention over a K/V cache [B][H][T_stride][64] -> bf16 head outputs att[B][H*64].
+// Keys 0 .. n-1 with n = *pos_ptr + 1 when pos_ptr != null, else n_keys.
+int wm_dec_attn_splits(int B, int H);
 int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
-                     int T_stride, int n_keys, int nsplit, float *part);
-// Reduce the per-tile packed maxima of a DE_LOGITS launch: next token -> cur[b] / history,
-// and (token - arg_first) -> result[b] (any of the three may be null).
-int wm_argmax_reduce(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *cur,
-                     int *history, int hist_stride, int hist_pos, int *result, int arg_first);
+                     int T_stride, int n_keys, const int *pos_ptr, int nsplit, float *part, bf16_t *att,
+                     bool cross);
+// Reduce the per-tile packed maxima of a DE_LOGITS launch (one workgroup): chosen token of row
+// b -> seq[(*pos_ptr + 1) * B + b] when that position is >= n_prompt; (token - arg_first) ->
+// result[b]; then *pos_ptr += 1.  seq / pos_ptr / result may be null.
+int wm_argmax_reduce(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
+                     int n_prompt, int *result, int arg_first);
 int wm_fill_synthetic(wm_ctx *ctx, const WmTensor &t, uint32_t seed, int tensor_id);

@@ -2,7 +2,9 @@
 // encoder / decoder entry points that replace the CoreML `encoder` / `decoder` classes
 // (Whisper/Whisper/Whisper.swift:17-40), the KV-cached greedy transcription asked for by
 // BASELINE.json, and the per-kernel test hooks (include/whisper_mi355x_debug.h).
+#include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -148,7 +150,8 @@ extern "C" int wm_decode_logits(wm_ctx *ctx, const int32_t *tokens, int B, int T
         }
     WM_TRY(wm_model_decode_begin(ctx, B));
     WM_TRY(load_xa(ctx, xa, B, mem));
-    WM_HIP(hipMemcpyAsync(m->dcur, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(hipMemcpyAsync(m->dseq, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    WM_TRY(wm_model_set_pos(ctx, 0));
     float *d_out = logits;
     char *st = nullptr;
     if (mem == WM_MEM_HOST) {
@@ -158,14 +161,17 @@ extern "C" int wm_decode_logits(wm_ctx *ctx, const int32_t *tokens, int B, int T
     }
     int rc = WM_OK;
     for (int t = 0; t < T && rc == WM_OK; ++t) {
-        rc = wm_model_decode_step(ctx, B, t, m->dcur + (size_t)t * B, true, false, 0, V - 1);
+        rc = wm_model_decode_step(ctx, B, true, 0, V - 1);
         if (rc != WM_OK) break;
         // dlogits [B][vpad] -> out [B][T][V], row t
         if (hipMemcpy2DAsync(d_out + (size_t)t * V, (size_t)T * V * 4, m->dlogits, (size_t)m->vpad * 4,
                              (size_t)V * 4, B, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
             wm_set_error("hipMemcpy2DAsync failed");
             rc = WM_ERR_HIP;
+            break;
         }
+        // teacher forcing: keep the given tokens, just advance the device-side position
+        rc = wm_argmax_reduce(ctx, m->dargmax, m->vpad / 16, B, nullptr, m->dpos, T, nullptr, 0);
     }
     if (rc == WM_OK && mem == WM_MEM_HOST) {
         if (hipMemcpyAsync(logits, d_out, (size_t)B * T * V * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
@@ -192,10 +198,10 @@ extern "C" int wm_detect_language(wm_ctx *ctx, const float *xa, int B, int32_t s
     WM_TRY(wm_model_decode_begin(ctx, B));
     WM_TRY(load_xa(ctx, xa, B, mem));
     std::vector<int32_t> sots(B, sot);  // Whisper.swift:34-35
-    WM_HIP(hipMemcpyAsync(m->dcur, sots.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
-    WM_HIP(hipStreamSynchronize(ctx->stream));  // sots is stack-lifetime
-    WM_TRY(wm_model_decode_step(ctx, B, 0, m->dcur, false, true, lang_first, lang_last));  // :36-37
-    WM_TRY(wm_argmax_reduce(ctx, m->dargmax, m->vpad / 16, B, nullptr, nullptr, 0, 0, m->dresult, lang_first));  // :38
+    WM_HIP(hipMemcpyAsync(m->dseq, sots.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+    WM_TRY(wm_model_set_pos(ctx, 0));                                       // also fences `sots`
+    WM_TRY(wm_model_decode_step(ctx, B, false, lang_first, lang_last));     // :36-37
+    WM_TRY(wm_argmax_reduce(ctx, m->dargmax, m->vpad / 16, B, nullptr, nullptr, 0, m->dresult, lang_first));  // :38
     std::vector<int32_t> res(B);
     WM_HIP(hipMemcpyAsync(res.data(), m->dresult, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));
@@ -258,22 +264,46 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
         std::vector<int32_t> pr((size_t)n_prompt * Bg);
         for (int t = 0; t < n_prompt; ++t)
             for (int b = 0; b < Bg; ++b) pr[(size_t)t * Bg + b] = prompt[t];
-        WM_HIP(hipMemcpyAsync(m->dcur, pr.data(), pr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        WM_HIP(hipStreamSynchronize(ctx->stream));
-        int *d_next = m->dcur + (size_t)n_prompt * Bg;  // generated token of the current step
-        for (int t = 0; t < n_prompt + max_new - 1 && rc == WM_OK; ++t) {
-            const bool gen = t >= n_prompt - 1;
-            const int *tok = t < n_prompt ? m->dcur + (size_t)t * Bg : d_next;
-            rc = wm_model_decode_step(ctx, Bg, t, tok, false, gen, 0, D.n_vocab - 1);
-            if (rc == WM_OK && gen)
-                rc = wm_argmax_reduce(ctx, m->dargmax, m->vpad / 16, Bg, d_next, m->dtokens, max_new,
-                                      t - (n_prompt - 1), nullptr, 0);
+        WM_HIP(hipMemcpyAsync(m->dseq, pr.data(), pr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = wm_model_set_pos(ctx, 0)) != WM_OK) break;
+        const int n_steps = n_prompt + max_new - 1;
+        // One decoder position = embed + 8 launches per layer + logits + arg-max (which writes
+        // the next token and advances *dpos).  Nothing in it depends on host state, so it is
+        // captured ONCE into a hipGraph and replayed for every position.
+        static const bool no_graph = getenv("WM_NO_GRAPH") != nullptr;
+        const bool use_graph = !no_graph && !ctx->prof.on;
+        if (use_graph && (m->graph_exec == nullptr || m->graph_B != Bg || m->graph_n_prompt != n_prompt ||
+                          m->graph_cap_b != m->cap_b)) {
+            if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+            if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+            WM_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            int crc = wm_model_decode_step(ctx, Bg, false, 0, D.n_vocab - 1);
+            if (crc == WM_OK)
+                crc = wm_argmax_reduce(ctx, m->dargmax, m->vpad / 16, Bg, m->dseq, m->dpos, n_prompt, nullptr, 0);
+            hipError_t ce = hipStreamEndCapture(ctx->stream, &m->graph);
+            if (crc != WM_OK) { rc = crc; break; }
+            WM_HIP(ce);
+            WM_HIP(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+            m->graph_B = Bg; m->graph_n_prompt = n_prompt; m->graph_cap_b = m->cap_b;
+        }
+        for (int t = 0; t < n_steps && rc == WM_OK; ++t) {
+            if (use_graph) {
+                WM_HIP(hipGraphLaunch(m->graph_exec, ctx->stream));
+            } else {
+                rc = wm_model_decode_step(ctx, Bg, false, 0, D.n_vocab - 1);
+                if (rc == WM_OK)
+                    rc = wm_argmax_reduce(ctx, m->dargmax, m->vpad / 16, Bg, m->dseq, m->dpos, n_prompt, nullptr, 0);
+            }
         }
         if (rc != WM_OK) break;
         WM_HIP(hipEventRecord(ev[3], ctx->stream));
-        std::vector<int32_t> hist((size_t)Bg * max_new);
-        WM_HIP(hipMemcpyAsync(hist.data(), m->dtokens, hist.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<int32_t> gen((size_t)max_new * Bg);  // dseq[n_prompt + i][b]
+        WM_HIP(hipMemcpyAsync(gen.data(), m->dseq + (size_t)n_prompt * Bg, gen.size() * 4, hipMemcpyDeviceToHost,
+                              ctx->stream));
         WM_HIP(hipStreamSynchronize(ctx->stream));
+        std::vector<int32_t> hist((size_t)Bg * max_new);
+        for (int b = 0; b < Bg; ++b)
+            for (int i = 0; i < max_new; ++i) hist[(size_t)b * max_new + i] = gen[(size_t)i * Bg + b];
         for (int b = 0; b < Bg; ++b) {
             int len = max_new;
             for (int i = 0; i < max_new; ++i)
@@ -423,7 +453,7 @@ extern "C" int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, co
     DecGemvArgs a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.N = N; a.K = K; a.W = (const bf16_t *)dW; a.bias = (const float *)dbias;
-    a.out_f32 = (float *)dout; a.ldo = N; a.epi = DE_Q;
+    a.out_f32 = (float *)dout; a.ldo = N; a.epi = DE_Q; a.pos_ptr = nullptr;
     if (ln_g) {
         WM_TRY(up(&dg, ln_g, (size_t)K * 4, s));
         WM_TRY(up(&db, ln_b, (size_t)K * 4, s));
@@ -458,26 +488,17 @@ extern "C" int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, 
     WM_TRY(up(&dk, k16.data(), k16.size() * 2, s));
     WM_TRY(up(&dv, v16.data(), v16.size() * 2, s));
     WM_TRY(up(&dp, nullptr, (size_t)B * H * nsplit * 66 * 4, s));
-    int rc = wm_dec_attention(ctx, (const float *)dq, (const bf16_t *)dk, (const bf16_t *)dv, B, H, T, n_keys, nsplit,
-                              (float *)dp);
+    void *datt;
+    WM_TRY(up(&datt, nullptr, (size_t)B * H * 64 * 2, s));
+    int rc = wm_dec_attention(ctx, (const float *)dq, (const bf16_t *)dk, (const bf16_t *)dv, B, H, T, n_keys, nullptr,
+                              nsplit, (float *)dp, (bf16_t *)datt, false);
     if (rc == WM_OK) {
-        std::vector<float> part((size_t)B * H * nsplit * 66);
-        WM_HIP(hipMemcpyAsync(part.data(), dp, part.size() * 4, hipMemcpyDeviceToHost, s));
+        std::vector<bf16_t> o16((size_t)B * H * 64);
+        WM_HIP(hipMemcpyAsync(o16.data(), datt, o16.size() * 2, hipMemcpyDeviceToHost, s));
         WM_HIP(hipStreamSynchronize(s));
-        for (int bh = 0; bh < B * H; ++bh) {
-            const float *pp = &part[(size_t)bh * nsplit * 66];
-            float Mx = -1e30f;
-            for (int i = 0; i < nsplit; ++i) Mx = pp[i * 66] > Mx ? pp[i * 66] : Mx;
-            double den = 0;
-            double num[64] = {0};
-            for (int i = 0; i < nsplit; ++i) {
-                const double w = exp((double)pp[i * 66] - Mx);
-                den += w * pp[i * 66 + 1];
-                for (int e = 0; e < 64; ++e) num[e] += w * pp[i * 66 + 2 + e];
-            }
-            for (int e = 0; e < 64; ++e) out[(size_t)bh * 64 + e] = (float)(num[e] / den);
-        }
+        from_bf16(o16, out);
     }
+    (void)hipFree(datt);
     (void)hipFree(dq); (void)hipFree(dk); (void)hipFree(dv); (void)hipFree(dp);
     return rc;
 }

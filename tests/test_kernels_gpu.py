@@ -145,7 +145,8 @@ def test_decode_gemv(ctx, B, N, K, ln):
 
 
 @pytest.mark.parametrize("B,H,T,n_keys,nsplit", [(2, 2, 448, 1, 1), (2, 2, 448, 37, 1), (1, 3, 448, 448, 1),
-                                                 (2, 2, 1500, 1500, 4), (1, 1, 1500, 1500, 3)])
+                                                 (2, 2, 1500, 1500, 4), (1, 1, 1500, 1500, 3), (8, 20, 1500, 1500, 1),
+                                                 (3, 2, 448, 130, 8)])
 def test_decode_attention(ctx, B, H, T, n_keys, nsplit):
     rng = np.random.default_rng(T + n_keys)
     q = rng.standard_normal((B, H * 64)).astype(np.float32)
@@ -160,12 +161,13 @@ def test_decode_attention(ctx, B, H, T, n_keys, nsplit):
     tv = torch.from_numpy(v[:, :, :n_keys]).double()
     w = torch.softmax(tq @ tk.transpose(-1, -2) / 8.0, dim=-1)
     ref = (w @ tv).reshape(B, H * 64).numpy()
-    assert np.abs(out - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    # head outputs are written as bf16 (they are the out-projection's MFMA operand)
+    assert np.abs(out - ref).max() <= 2 ** -8 * max(1.0, np.abs(ref).max())
 
 
-def test_decode_attention_rejects_oversized_split(ctx):
+def test_decode_attention_rejects_bad_split(ctx):
     q = np.zeros((1, 64), np.float32)
-    k = np.zeros((1, 1, 1500, 64), np.float32)
+    k = np.zeros((1, 1, 64, 64), np.float32)
     out = np.zeros((1, 64), np.float32)
-    assert ctx.lib.wmdbg_dec_attention(ctx.handle, P(q), P(k), P(k), 1, 1, 1500, 1500, 2, P(out)) == 1
-    assert b"512-key" in ctx.lib.wm_last_error()
+    assert ctx.lib.wmdbg_dec_attention(ctx.handle, P(q), P(k), P(k), 1, 1, 64, 64, 9, P(out)) == 1
+    assert b"nsplit" in ctx.lib.wm_last_error()
