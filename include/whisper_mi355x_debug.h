@@ -41,6 +41,13 @@ int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, const float *
 int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, const float *v, int B, int H, int T,
                         int n_keys, int nsplit, float *out);
 
+/* ---- micro-benchmarks: average microseconds per launch over `iters` back-to-back launches
+ * that cycle over n_mats weight matrices / n_slices cache slices (defeats L2 / MALL reuse). */
+int wmdbg_bench_dec_gemv(wm_ctx *ctx, int B, int N, int K, int ln, int resid, int n_mats, int iters,
+                         int nw_override, float *avg_us);
+int wmdbg_bench_dec_attention(wm_ctx *ctx, int B, int H, int T, int n_keys, int nsplit, int n_slices,
+                              int iters, float *avg_us);
+
 #ifdef __cplusplus
 }
 #endif

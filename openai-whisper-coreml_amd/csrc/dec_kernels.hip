@@ -61,35 +61,17 @@ struct DecGemvDev {
     int arg_first, arg_last;
 };
 
-// G k-steps: all G weight loads (16 B per lane each) are issued before the first MFMA.
-// A fragments come either from the wave-private LDS image built by the LayerNorm prologue
-// or straight from a bf16 activation row in L2 -- always UNCONDITIONAL loads from a clamped
-// row (a lane-divergent branch around a load makes hipcc serialise it behind
-// s_waitcnt vmcnt(0): 10 dependent L2 round trips per wave, measured ~10 us per launch).
-template <int AMODE, int G>
-__device__ __forceinline__ void gemv_group(const bf16_t *wp, int s0, const char *xs_row, const bf16_t *a_row,
-                                           int kq, bool live, f32x4 &acc) {
-    u32x4 wf[G], af[G];
-#pragma unroll
-    for (int u = 0; u < G; ++u) wf[u] = __builtin_nontemporal_load((const u32x4 *)(wp + (s0 + u) * 32));
-#pragma unroll
-    for (int u = 0; u < G; ++u) {
-        if (AMODE == DA_LN)
-            af[u] = *(const u32x4 *)(xs_row + ((s0 + u) * 32 + kq * 8) * 2);
-        else
-            af[u] = *(const u32x4 *)(a_row + (s0 + u) * 32 + kq * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < G; ++u) {
-        u32x4 av = af[u];
-        if (!live) av = (u32x4){0u, 0u, 0u, 0u};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av),
-                                                      __builtin_bit_cast(bf16x8, wf[u]), acc, 0, 0, 0);
-    }
-}
+// Weight stream of one wave: WG_MAX k-steps are issued up front, unconditionally (steps past
+// the wave's range re-read its last fragment: an L1 hit, no HBM traffic), BEFORE the LayerNorm
+// prologue, so the HBM latency of the weights overlaps the statistics.  A fragments come from
+// the wave-private LDS image built by the prologue, or straight from a bf16 activation row in
+// L2 -- always unconditional loads from a clamped row: a lane-divergent branch around a load
+// makes hipcc serialise it behind s_waitcnt vmcnt(0) (measured: 10 dependent L2 round trips
+// per wave, ~10 us per launch).
+constexpr int WG_MAX = 12;
 
 // LDS carve (dynamic): red [NW][64][4] f32 | part [2][NW][16] f32 | xs [NW][B][KC+8] bf16 (DA_LN)
-template <int AMODE, int EPI, int NW, int BMAX>
+template <int AMODE, int EPI, int NW>
 __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *red = (float *)smem;
@@ -100,108 +82,142 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
     const int n0 = blockIdx.x * 16;
     const int kbase = wave * p.KC;
     const int nsteps = p.KC >> 5;
-    const bf16_t *wp = p.W + (long)(n0 + nrow) * p.K + kbase + kq * 8;
+    // fragment-tiled weights (WL_TILED): k-step s of n-tile t is the contiguous KiB at
+    // ((t * K/32 + s) * 64 + lane) * 8 -- one perfectly coalesced dwordx4 per lane per step
+    const bf16_t *wp = p.W + (((long)blockIdx.x * (p.K >> 5) + (long)wave * nsteps) * 64 + lane) * 8;
     const bool live = nrow < p.B;
     const int rowc = live ? nrow : p.B - 1;  // clamped batch row for unconditional loads
     const int xs_stride = (p.KC + 8) * 2;    // bytes; the 16 B pad keeps ds_read_b128 conflict-free
     char *xs = xs_all + (long)wave * p.B * xs_stride;
 
+    // ---- 1. weight stream in flight first ---------------------------------------------------
+    u32x4 wf[WG_MAX];
+#pragma unroll
+    for (int u = 0; u < WG_MAX; ++u) {
+        const int sc = u < nsteps ? u : nsteps - 1;
+        wf[u] = __builtin_nontemporal_load((const u32x4 *)(wp + sc * 512));
+    }
+
     if (AMODE == DA_LN) {
-        // ---- fused LayerNorm: this wave normalises x[0..B)[kbase .. kbase+KC) ---------------
-        // lane owns float4 columns j4 = lane + 64*u; two-pass fp32 statistics across the
-        // workgroup (a row is split over the NW waves along K).
+        // ---- 2. fused LayerNorm: this wave normalises x[0..B)[kbase .. kbase+KC) ------------
+        // lane owns float4 columns j4 = lane and lane + 64 (KC <= 512); rows in groups of 8;
+        // two-pass fp32 statistics across the workgroup (a row is split over the NW waves).
         const int kc4 = p.KC >> 2;
-        constexpr int UMAX = 3;
-        float4 xv[BMAX][UMAX];
-        int j4c[UMAX];
-        bool jv[UMAX];
+        int j4c[2];
+        float jm[2];
 #pragma unroll
-        for (int u = 0; u < UMAX; ++u) {
+        for (int u = 0; u < 2; ++u) {
             const int j4 = lane + 64 * u;
-            jv[u] = j4 < kc4;
-            j4c[u] = jv[u] ? j4 : kc4 - 1;
+            jm[u] = j4 < kc4 ? 1.f : 0.f;
+            j4c[u] = j4 < kc4 ? j4 : kc4 - 1;
         }
+        float4 gv[2], bv[2];
 #pragma unroll
-        for (int b = 0; b < BMAX; ++b) {
-            const int bc = b < p.B ? b : p.B - 1;
-#pragma unroll
-            for (int u = 0; u < UMAX; ++u)
-                xv[b][u] = *(const float4 *)(p.x + (long)bc * p.K + kbase + 4 * j4c[u]);
-        }
-        float4 gv[UMAX], bv[UMAX];
-#pragma unroll
-        for (int u = 0; u < UMAX; ++u) {
+        for (int u = 0; u < 2; ++u) {
             gv[u] = *(const float4 *)(p.ln_g + kbase + 4 * j4c[u]);
             bv[u] = *(const float4 *)(p.ln_b + kbase + 4 * j4c[u]);
         }
-        // pass 1: row sums
+        for (int b0 = 0; b0 < p.B; b0 += 8) {  // wave-uniform: 1 or 2 trips
+            float4 xv[8][2];
 #pragma unroll
-        for (int b = 0; b < BMAX; ++b) {
-            float s = 0.f;
+            for (int b = 0; b < 8; ++b) {
+                const int bc = b0 + b < p.B ? b0 + b : p.B - 1;
 #pragma unroll
-            for (int u = 0; u < UMAX; ++u)
-                if (jv[u]) s += (xv[b][u].x + xv[b][u].y) + (xv[b][u].z + xv[b][u].w);
+                for (int u = 0; u < 2; ++u)
+                    xv[b][u] = *(const float4 *)(p.x + (long)bc * p.K + kbase + 4 * j4c[u]);
+            }
+            // pass 1: row sums
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) part[wave * 16 + b] = s;
-        }
-        __syncthreads();
-        float mean[BMAX];
+            for (int b = 0; b < 8; ++b) {
+                float s = ((xv[b][0].x + xv[b][0].y) + (xv[b][0].z + xv[b][0].w)) * jm[0] +
+                          ((xv[b][1].x + xv[b][1].y) + (xv[b][1].z + xv[b][1].w)) * jm[1];
 #pragma unroll
-        for (int b = 0; b < BMAX; ++b) {
-            float s = 0.f;
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                if (lane == 0) part[wave * 16 + b] = s;
+            }
+            __syncthreads();
+            float mean[8];
 #pragma unroll
-            for (int w = 0; w < NW; ++w) s += part[w * 16 + b];
-            mean[b] = s / (float)p.K;
-        }
-        // pass 2: centred second moment
+            for (int b = 0; b < 8; ++b) {
+                float s = 0.f;
 #pragma unroll
-        for (int b = 0; b < BMAX; ++b) {
-            float q = 0.f;
+                for (int w = 0; w < NW; ++w) s += part[w * 16 + b];
+                mean[b] = s / (float)p.K;
+            }
+            // pass 2: centred second moment
 #pragma unroll
-            for (int u = 0; u < UMAX; ++u)
-                if (jv[u]) {
+            for (int b = 0; b < 8; ++b) {
+                float q = 0.f;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
                     const float a0 = xv[b][u].x - mean[b], a1 = xv[b][u].y - mean[b];
                     const float a2 = xv[b][u].z - mean[b], a3 = xv[b][u].w - mean[b];
-                    q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                    q += ((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) * jm[u];
                 }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-            if (lane == 0) part[NW * 16 + wave * 16 + b] = q;
-        }
-        __syncthreads();
+                for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+                if (lane == 0) part[NW * 16 + wave * 16 + b] = q;
+            }
+            __syncthreads();
 #pragma unroll
-        for (int b = 0; b < BMAX; ++b) {
-            if (b < p.B) {  // wave-uniform
+            for (int b = 0; b < 8; ++b) {
                 float q = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) q += part[NW * 16 + w * 16 + b];
                 const float rstd = rsqrtf(q / (float)p.K + 1e-5f);
+                const int br = b0 + b < p.B ? b0 + b : p.B - 1;  // duplicate rows rewrite row B-1 with equal data
 #pragma unroll
-                for (int u = 0; u < UMAX; ++u)
-                    if (jv[u]) {
-                        const unsigned lo = pack2((xv[b][u].x - mean[b]) * rstd * gv[u].x + bv[u].x,
-                                                  (xv[b][u].y - mean[b]) * rstd * gv[u].y + bv[u].y);
-                        const unsigned hi = pack2((xv[b][u].z - mean[b]) * rstd * gv[u].z + bv[u].z,
-                                                  (xv[b][u].w - mean[b]) * rstd * gv[u].w + bv[u].w);
-                        *(uint2 *)(xs + b * xs_stride + (lane + 64 * u) * 8) = make_uint2(lo, hi);
-                    }
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned lo = pack2((xv[b][u].x - mean[b]) * rstd * gv[u].x + bv[u].x,
+                                              (xv[b][u].y - mean[b]) * rstd * gv[u].y + bv[u].y);
+                    const unsigned hi = pack2((xv[b][u].z - mean[b]) * rstd * gv[u].z + bv[u].z,
+                                              (xv[b][u].w - mean[b]) * rstd * gv[u].w + bv[u].w);
+                    // clamped column: lanes past the chunk rewrite column kc4-1 with equal data
+                    *(uint2 *)(xs + br * xs_stride + j4c[u] * 8) = make_uint2(lo, hi);
+                }
             }
+            __syncthreads();  // part[] is reused by the next row group
         }
-        __syncthreads();
     }
 
+    // ---- 3. A fragments + MFMA ---------------------------------------------------------------
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const char *xs_row = xs + rowc * xs_stride;
     const bf16_t *a_row = (AMODE == DA_BF16) ? p.a_bf16 + (long)rowc * p.K + kbase : nullptr;
-    int s0 = 0;
-    if (nsteps % 12 == 0)
-        for (; s0 + 12 <= nsteps; s0 += 12) gemv_group<AMODE, 12>(wp, s0, xs_row, a_row, kq, live, acc);
-    if (nsteps % 10 == 0)
-        for (; s0 + 10 <= nsteps; s0 += 10) gemv_group<AMODE, 10>(wp, s0, xs_row, a_row, kq, live, acc);
-    for (; s0 + 8 <= nsteps; s0 += 8) gemv_group<AMODE, 8>(wp, s0, xs_row, a_row, kq, live, acc);
-    for (; s0 + 2 <= nsteps; s0 += 2) gemv_group<AMODE, 2>(wp, s0, xs_row, a_row, kq, live, acc);
-    for (; s0 < nsteps; ++s0) gemv_group<AMODE, 1>(wp, s0, xs_row, a_row, kq, live, acc);
+    u32x4 af[WG_MAX];
+#pragma unroll
+    for (int u = 0; u < WG_MAX; ++u) {
+        const int sc = u < nsteps ? u : nsteps - 1;
+        if (AMODE == DA_LN)
+            af[u] = *(const u32x4 *)(xs_row + (sc * 32 + kq * 8) * 2);
+        else
+            af[u] = *(const u32x4 *)(a_row + sc * 32 + kq * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < WG_MAX; ++u) {
+        u32x4 av = af[u];
+        if (!live || u >= nsteps) av = (u32x4){0u, 0u, 0u, 0u};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av),
+                                                      __builtin_bit_cast(bf16x8, wf[u]), acc, 0, 0, 0);
+    }
+    // generic tail (KC > 384): two steps at a time
+    for (int s0 = WG_MAX; s0 < nsteps; s0 += 2) {
+        u32x4 w2[2], a2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int sc = s0 + u < nsteps ? s0 + u : nsteps - 1;
+            w2[u] = __builtin_nontemporal_load((const u32x4 *)(wp + sc * 512));
+            a2[u] = (AMODE == DA_LN) ? *(const u32x4 *)(xs_row + (sc * 32 + kq * 8) * 2)
+                                     : *(const u32x4 *)(a_row + sc * 32 + kq * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            u32x4 av = a2[u];
+            if (!live || s0 + u >= nsteps) av = (u32x4){0u, 0u, 0u, 0u};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av),
+                                                          __builtin_bit_cast(bf16x8, w2[u]), acc, 0, 0, 0);
+        }
+    }
 
     // ---- cross-wave (split-K) reduction through LDS ----------------------------------------
     if (NW > 1) {
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int *__restrict__ 
     const int pos = *pos_ptr;
     const long tok = seq[pos * B + b];
     for (int j = threadIdx.x; j < d; j += 256)
-        x[(long)b * d + j] = bf2f(emb[tok * d + j]) + pemb[(long)pos * d + j];
+        x[(long)b * d + j] = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)pos * d + j];
 }
 
 // ------------------------------------------------------------------ single-query attention
@@ -488,6 +504,8 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(void *dst, int is_bf16,
             const size_t per = (size_t)conv_c * 3;
             const size_t oc = i / per, rem = i % per, c = rem / 3, tap = rem % 3;
             o = oc * kpad + tap * conv_c + c;
+        } else if (layout == WL_TILED) {
+            o = wm_tiled_offset(i / (size_t)kpad, i % (size_t)kpad, (size_t)kpad);
         }
         if (is_bf16)
             ((bf16_t *)dst)[o] = f2bf(v);
@@ -496,45 +514,47 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(void *dst, int is_bf16,
     }
 }
 
-template <int AMODE, int EPI, int BMAX>
-int launch_gemv(wm_ctx *ctx, const DecGemvDev &p, int nw, int grid) {
+template <int AMODE, int EPI>
+int launch_gemv_b(wm_ctx *ctx, const DecGemvDev &p, int nw, int grid) {
     hipStream_t s = ctx->stream;
     size_t lds = (size_t)nw * 1024 + 2 * nw * 16 * 4;
     if (AMODE == DA_LN) lds += (size_t)nw * p.B * (p.KC + 8) * 2;
     lds = (lds + 15) & ~(size_t)15;
     switch (nw) {
-        case 1: dec_gemv_kernel<AMODE, EPI, 1, BMAX><<<grid, 64, lds, s>>>(p); break;
-        case 2: dec_gemv_kernel<AMODE, EPI, 2, BMAX><<<grid, 128, lds, s>>>(p); break;
-        case 4: dec_gemv_kernel<AMODE, EPI, 4, BMAX><<<grid, 256, lds, s>>>(p); break;
-        case 8: dec_gemv_kernel<AMODE, EPI, 8, BMAX><<<grid, 512, lds, s>>>(p); break;
-        case 16: dec_gemv_kernel<AMODE, EPI, 16, BMAX><<<grid, 1024, lds, s>>>(p); break;
-        default: wm_set_error("dec_gemv: bad wave count %d", nw); return WM_ERR_INVALID;
+        case 1: dec_gemv_kernel<AMODE, EPI, 1><<<grid, 64, lds, s>>>(p); break;
+        case 2: dec_gemv_kernel<AMODE, EPI, 2><<<grid, 128, lds, s>>>(p); break;
+        case 4: dec_gemv_kernel<AMODE, EPI, 4><<<grid, 256, lds, s>>>(p); break;
+        case 8:
+            if (AMODE == DA_BF16) { dec_gemv_kernel<DA_BF16, EPI, 8><<<grid, 512, lds, s>>>(p); break; }
+        case 16:
+            if (AMODE == DA_BF16) { dec_gemv_kernel<DA_BF16, EPI, 16><<<grid, 1024, lds, s>>>(p); break; }
+        default: wm_set_error("dec_gemv: unsupported wave count %d for this mode", nw); return WM_ERR_INVALID;
     }
     WM_HIP(hipGetLastError());
     return WM_OK;
 }
 
-template <int AMODE, int EPI>
-int launch_gemv_b(wm_ctx *ctx, const DecGemvDev &p, int nw, int grid) {
-    if (AMODE == DA_LN && p.B > 8) return launch_gemv<AMODE, EPI, 16>(ctx, p, nw, grid);
-    return launch_gemv<AMODE, EPI, 8>(ctx, p, nw, grid);
-}
-
 }  // namespace
 
+// Waves per workgroup (= K splits inside the workgroup).  Target 256..384 k per wave (8..12
+// MFMA k-steps, all issued up front); the LayerNorm prologue needs KC <= 512 and NW <= 4.
+static int g_nw_override = 0;
+void wm_dec_gemv_set_waves_override(int nw) { g_nw_override = nw; }
 static int pick_waves(int K, bool ln) {
-    int nw = 16;
-    while (nw > 1 && (K / 256 < nw || K % (32 * nw) != 0)) nw >>= 1;
-    // the LayerNorm prologue holds KC/4 float4 columns in at most 3 x 64 lanes: KC <= 768
-    while (ln && K / nw > 768 && nw < 16) nw <<= 1;
-    return nw;
+    if (g_nw_override > 0 && K % (32 * g_nw_override) == 0 && (!ln || (g_nw_override <= 4 && K / g_nw_override <= 512)))
+        return g_nw_override;
+    const int maxw = ln ? 4 : 16;
+    int best = 1;
+    for (int nw = 1; nw <= maxw; nw <<= 1)
+        if (K % (32 * nw) == 0 && K / nw >= 256) best = nw;
+    return best;
 }
 
 int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     WM_REQUIRE(a.B >= 1 && a.B <= WM_DEC_MAXB, WM_ERR_INVALID, "dec_gemv: B=%d out of range", a.B);
     WM_REQUIRE(a.K % 32 == 0, WM_ERR_INVALID, "dec_gemv: K=%d must be a multiple of 32", a.K);
     const int nw = pick_waves(a.K, a.a_mode == DA_LN);
-    WM_REQUIRE(a.K % (32 * nw) == 0 && (a.a_mode != DA_LN || a.K / nw <= 768), WM_ERR_INVALID,
+    WM_REQUIRE(a.K % (32 * nw) == 0 && (a.a_mode != DA_LN || a.K / nw <= 512), WM_ERR_INVALID,
                "dec_gemv: K=%d cannot be split over %d waves", a.K, nw);
     DecGemvDev p;
     p.B = a.B; p.N = a.N; p.K = a.K; p.KC = a.K / nw;

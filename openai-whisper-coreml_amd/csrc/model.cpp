@@ -72,23 +72,26 @@ int wm_model_create(wm_ctx *ctx, const wm_dims *dims) {
     reg(m, "encoder.conv2.bias", m->conv2_b, false, d, 1);
     reg(m, "encoder.positional_embedding", m->enc_pos, false, (size_t)D.n_audio_ctx * d, 4);
 
+    // lq / lkv / lo: HBM layout of the query, key+value and out matrices (decode GEMV operands are
+    // stored fragment-tiled; GEMM operands row-major)
     auto attn_regs = [&](const std::string &p, bf16_t *wq, float *bq, bf16_t *wk, bf16_t *wv, float *bv,
-                         bf16_t *wo, float *bo, float *lg, float *lb, const char *a) {
+                         bf16_t *wo, float *bo, float *lg, float *lb, const char *a, int lq, int lkv, int lo) {
         const size_t dd = (size_t)d * d;
-        reg(m, p + "." + a + ".query.weight", wq, true, dd, 0);
+        reg(m, p + "." + a + ".query.weight", wq, true, dd, 0, lq, 0, d);
         reg(m, p + "." + a + ".query.bias", bq, false, d, 1);
-        reg(m, p + "." + a + ".key.weight", wk, true, dd, 0);
-        reg(m, p + "." + a + ".value.weight", wv, true, dd, 0);
+        reg(m, p + "." + a + ".key.weight", wk, true, dd, 0, lkv, 0, d);
+        reg(m, p + "." + a + ".value.weight", wv, true, dd, 0, lkv, 0, d);
         reg(m, p + "." + a + ".value.bias", bv, false, d, 1);
-        reg(m, p + "." + a + ".out.weight", wo, true, dd, 0);
+        reg(m, p + "." + a + ".out.weight", wo, true, dd, 0, lo, 0, d);
         reg(m, p + "." + a + ".out.bias", bo, false, d, 1);
         reg(m, p + "." + a + "_ln.weight", lg, false, d, 2);
         reg(m, p + "." + a + "_ln.bias", lb, false, d, 3);
     };
-    auto mlp_regs = [&](const std::string &p, bf16_t *w1, float *b1, bf16_t *w2, float *b2, float *lg, float *lb) {
-        reg(m, p + ".mlp.0.weight", w1, true, (size_t)4 * d * d, 0);
+    auto mlp_regs = [&](const std::string &p, bf16_t *w1, float *b1, bf16_t *w2, float *b2, float *lg, float *lb,
+                        int lay) {
+        reg(m, p + ".mlp.0.weight", w1, true, (size_t)4 * d * d, 0, lay, 0, d);
         reg(m, p + ".mlp.0.bias", b1, false, 4 * d, 1);
-        reg(m, p + ".mlp.2.weight", w2, true, (size_t)4 * d * d, 0);
+        reg(m, p + ".mlp.2.weight", w2, true, (size_t)4 * d * d, 0, lay, 0, 4 * d);
         reg(m, p + ".mlp.2.bias", b2, false, d, 1);
         reg(m, p + ".mlp_ln.weight", lg, false, d, 2);
         reg(m, p + ".mlp_ln.bias", lb, false, d, 3);
@@ -105,8 +108,8 @@ int wm_model_create(wm_ctx *ctx, const wm_dims *dims) {
         WM_TRY(dalloc_t(m, &L.w2, (size_t)4 * d * d, s)); WM_TRY(dalloc_t(m, &L.b2, d, s));
         const std::string p = "encoder.blocks." + std::to_string(i);
         attn_regs(p, L.wqkv, L.bqkv, L.wqkv + (size_t)d * d, L.wqkv + (size_t)2 * d * d, L.bqkv + 2 * d, L.wo,
-                  L.bo, L.ln1_g, L.ln1_b, "attn");
-        mlp_regs(p, L.w1, L.b1, L.w2, L.b2, L.ln2_g, L.ln2_b);
+                  L.bo, L.ln1_g, L.ln1_b, "attn", WL_PLAIN, WL_PLAIN, WL_PLAIN);
+        mlp_regs(p, L.w1, L.b1, L.w2, L.b2, L.ln2_g, L.ln2_b, WL_PLAIN);
     }
     WM_TRY(dalloc_t(m, &m->ln_post_g, d, s)); WM_TRY(dalloc_t(m, &m->ln_post_b, d, s));
     reg(m, "encoder.ln_post.weight", m->ln_post_g, false, d, 2);
@@ -114,7 +117,7 @@ int wm_model_create(wm_ctx *ctx, const wm_dims *dims) {
 
     WM_TRY(dalloc_t(m, &m->tok_emb, (size_t)m->vpad * d, s));
     WM_TRY(dalloc_t(m, &m->dec_pos, (size_t)D.n_text_ctx * d, s));
-    reg(m, "decoder.token_embedding.weight", m->tok_emb, true, (size_t)D.n_vocab * d, 0);
+    reg(m, "decoder.token_embedding.weight", m->tok_emb, true, (size_t)D.n_vocab * d, 0, WL_TILED, 0, d);
     reg(m, "decoder.positional_embedding", m->dec_pos, false, (size_t)D.n_text_ctx * d, 0);
     m->dec.resize(D.n_text_layer);
     for (int i = 0; i < D.n_text_layer; ++i) {
@@ -131,10 +134,11 @@ int wm_model_create(wm_ctx *ctx, const wm_dims *dims) {
         WM_TRY(dalloc_t(m, &L.w2, (size_t)4 * d * d, s)); WM_TRY(dalloc_t(m, &L.b2, d, s));
         const std::string p = "decoder.blocks." + std::to_string(i);
         attn_regs(p, L.wqkv, L.bqkv, L.wqkv + (size_t)d * d, L.wqkv + (size_t)2 * d * d, L.bqkv + 2 * d, L.wo,
-                  L.bo, L.ln1_g, L.ln1_b, "attn");
+                  L.bo, L.ln1_g, L.ln1_b, "attn", WL_TILED, WL_TILED, WL_TILED);
+        // cross-attention key/value matrices feed the big GEMM (row-major); query/out feed the GEMV
         attn_regs(p, L.wxq, L.bxq, L.wxkv, L.wxkv + (size_t)d * d, L.bxkv + d, L.wxo, L.bxo, L.lnx_g, L.lnx_b,
-                  "cross_attn");
-        mlp_regs(p, L.w1, L.b1, L.w2, L.b2, L.ln2_g, L.ln2_b);
+                  "cross_attn", WL_TILED, WL_PLAIN, WL_TILED);
+        mlp_regs(p, L.w1, L.b1, L.w2, L.b2, L.ln2_g, L.ln2_b, WL_TILED);
     }
     WM_TRY(dalloc_t(m, &m->ln_g, d, s)); WM_TRY(dalloc_t(m, &m->ln_b, d, s));
     reg(m, "decoder.ln.weight", m->ln_g, false, d, 2);
@@ -182,6 +186,13 @@ int wm_model_set_tensor(wm_ctx *ctx, const char *name, const float *data, size_t
         std::vector<bf16_t> tmp(n);
         for (size_t i = 0; i < n; ++i) tmp[i] = host_f2bf(data[i]);
         WM_HIP(hipMemcpy(t.ptr, tmp.data(), n * sizeof(bf16_t), hipMemcpyHostToDevice));
+    } else if (t.layout == WL_TILED) {
+        const size_t K = (size_t)t.conv_kpad, N = n / K;
+        const size_t Np = (N + 15) / 16 * 16;
+        std::vector<bf16_t> tmp(Np * K, 0);
+        for (size_t r = 0; r < N; ++r)
+            for (size_t k = 0; k < K; ++k) tmp[wm_tiled_offset(r, k, K)] = host_f2bf(data[r * K + k]);
+        WM_HIP(hipMemcpy(t.ptr, tmp.data(), tmp.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
     } else {  // WL_CONV: [O][C][3] -> [O][kpad], k = tap*C + c
         const size_t per = (size_t)t.conv_c * 3, O = n / per;
         std::vector<bf16_t> tmp(O * t.conv_kpad, 0);
@@ -211,6 +222,13 @@ int wm_model_get_tensor(wm_ctx *ctx, const char *name, float *data, size_t n) {
         std::vector<bf16_t> tmp(n);
         WM_HIP(hipMemcpy(tmp.data(), t.ptr, n * sizeof(bf16_t), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < n; ++i) data[i] = host_bf2f(tmp[i]);
+    } else if (t.layout == WL_TILED) {
+        const size_t K = (size_t)t.conv_kpad, N = n / K;
+        const size_t Np = (N + 15) / 16 * 16;
+        std::vector<bf16_t> tmp(Np * K);
+        WM_HIP(hipMemcpy(tmp.data(), t.ptr, tmp.size() * sizeof(bf16_t), hipMemcpyDeviceToHost));
+        for (size_t r = 0; r < N; ++r)
+            for (size_t k = 0; k < K; ++k) data[r * K + k] = host_bf2f(tmp[wm_tiled_offset(r, k, K)]);
     } else {
         const size_t per = (size_t)t.conv_c * 3, O = n / per;
         std::vector<bf16_t> tmp(O * t.conv_kpad);

@@ -41,7 +41,14 @@ struct DecLayerW {
 };
 
 // One registry entry per openai-whisper state-dict key: where its elements live in HBM.
-enum WmLayout { WL_PLAIN = 0, WL_CONV = 1 };  // WL_CONV: [O][C][3] -> [O][Kpad], k = tap*C + c
+// WL_CONV : [O][C][3] -> [O][Kpad], k = tap*C + c (conv taps made contiguous for the implicit GEMM)
+// WL_TILED: [N][K] -> MFMA-fragment-major tiles for the decode GEMV: tile (n/16, k/32) is the
+//           1 KiB a wave loads with ONE global_load_dwordx4 (lane = n%16 + 16*((k%32)/8), 8 k
+//           per lane), tiles ordered n-tile major, k-step minor -- a wave streams contiguous KiBs.
+enum WmLayout { WL_PLAIN = 0, WL_CONV = 1, WL_TILED = 2 };
+__host__ __device__ static inline size_t wm_tiled_offset(size_t n, size_t k, size_t K) {
+    return (((n >> 4) * (K >> 5) + (k >> 5)) * 64 + (n & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7);
+}
 struct WmTensor {
     std::string name;
     void *ptr = nullptr;  // destination of logical element 0
@@ -168,7 +175,7 @@ enum DecEpi { DE_QKV = 0, DE_Q = 1, DE_RESID = 2, DE_GELU = 3, DE_LOGITS = 4 };
 struct DecGemvArgs {
     int a_mode, epi;
     int B, N, K;
-    const bf16_t *W;    // [N (padded to 16)][K]
+    const bf16_t *W;    // [N (padded to 16)][K] in WL_TILED order
     const float *bias;  // [N] or null
     // A operand
     const float *x;        // DA_LN: residual stream [B][K]

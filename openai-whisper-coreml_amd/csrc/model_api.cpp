@@ -441,8 +441,9 @@ extern "C" int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, co
     WM_TRY(wm_ctx_make_current(ctx));
     const int Npad = ((N + 15) / 16) * 16;
     std::vector<bf16_t> w16, x16;
-    std::vector<float> wp((size_t)Npad * K, 0.f);
-    memcpy(wp.data(), W, (size_t)N * K * 4);
+    std::vector<float> wp((size_t)Npad * K, 0.f);   // fragment-tiled order (WL_TILED)
+    for (size_t r = 0; r < (size_t)N; ++r)
+        for (size_t k = 0; k < (size_t)K; ++k) wp[wm_tiled_offset(r, k, (size_t)K)] = W[r * K + k];
     to_bf16(wp.data(), w16, wp.size());
     void *dx, *dx16 = nullptr, *dg = nullptr, *db = nullptr, *dW, *dbias = nullptr, *dout;
     hipStream_t s = ctx->stream;
@@ -500,5 +501,86 @@ extern "C" int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, 
     }
     (void)hipFree(datt);
     (void)hipFree(dq); (void)hipFree(dk); (void)hipFree(dv); (void)hipFree(dp);
+    return rc;
+}
+
+// ------------------------------------------------------------------ micro-benchmarks ------
+// Time `iters` back-to-back launches of one decode kernel, cycling over `n_mats` distinct weight
+// matrices / cache slices so nothing is served from L2 or MALL.  Returns average microseconds
+// per launch (HIP events on the context's stream).
+void wm_dec_gemv_set_waves_override(int nw);
+
+extern "C" int wmdbg_bench_dec_gemv(wm_ctx *ctx, int B, int N, int K, int ln, int resid, int n_mats, int iters,
+                                    int nw_override, float *avg_us) {
+    WM_TRY(wm_ctx_make_current(ctx));
+    hipStream_t s = ctx->stream;
+    const int Npad = ((N + 15) / 16) * 16;
+    void *dW, *dx, *dx16, *dg, *db, *dout;
+    WM_TRY(up(&dW, nullptr, (size_t)n_mats * Npad * K * 2, s));
+    WM_TRY(up(&dx, nullptr, (size_t)16 * K * 4, s));
+    WM_TRY(up(&dx16, nullptr, (size_t)16 * K * 2, s));
+    WM_TRY(up(&dg, nullptr, (size_t)K * 4, s));
+    WM_TRY(up(&db, nullptr, (size_t)K * 4, s));
+    WM_TRY(up(&dout, nullptr, (size_t)16 * Npad * 4, s));
+    WM_HIP(hipMemsetAsync(dW, 0x3c, (size_t)n_mats * Npad * K * 2, s));
+    DecGemvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.N = N; a.K = K; a.out_f32 = (float *)dout; a.ldo = Npad; a.epi = resid ? DE_RESID : DE_Q;
+    if (ln) { a.a_mode = DA_LN; a.x = (const float *)dx; a.ln_g = (const float *)dg; a.ln_b = (const float *)db; }
+    else { a.a_mode = DA_BF16; a.a_bf16 = (const bf16_t *)dx16; }
+    wm_dec_gemv_set_waves_override(nw_override);
+    hipEvent_t e0, e1;
+    WM_HIP(hipEventCreate(&e0));
+    WM_HIP(hipEventCreate(&e1));
+    int rc = WM_OK;
+    for (int pass = 0; pass < 2 && rc == WM_OK; ++pass) {
+        if (pass == 1) WM_HIP(hipEventRecord(e0, s));
+        for (int i = 0; i < iters && rc == WM_OK; ++i) {
+            a.W = (const bf16_t *)dW + (size_t)(i % n_mats) * Npad * K;
+            rc = wm_dec_gemv(ctx, a);
+        }
+    }
+    wm_dec_gemv_set_waves_override(0);
+    WM_HIP(hipEventRecord(e1, s));
+    WM_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    WM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = ms * 1e3f / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    void *fr[] = {dW, dx, dx16, dg, db, dout};
+    for (void *p : fr) (void)hipFree(p);
+    return rc;
+}
+
+extern "C" int wmdbg_bench_dec_attention(wm_ctx *ctx, int B, int H, int T, int n_keys, int nsplit, int n_slices,
+                                         int iters, float *avg_us) {
+    WM_TRY(wm_ctx_make_current(ctx));
+    hipStream_t s = ctx->stream;
+    const size_t slice = (size_t)B * H * T * 64;
+    void *dk, *dv, *dq, *dp, *datt;
+    WM_TRY(up(&dk, nullptr, slice * n_slices * 2, s));
+    WM_TRY(up(&dv, nullptr, slice * n_slices * 2, s));
+    WM_TRY(up(&dq, nullptr, (size_t)B * H * 64 * 4, s));
+    WM_TRY(up(&dp, nullptr, (size_t)B * H * 8 * 66 * 4, s));
+    WM_TRY(up(&datt, nullptr, (size_t)B * H * 64 * 2, s));
+    hipEvent_t e0, e1;
+    WM_HIP(hipEventCreate(&e0));
+    WM_HIP(hipEventCreate(&e1));
+    int rc = WM_OK;
+    for (int pass = 0; pass < 2 && rc == WM_OK; ++pass) {
+        if (pass == 1) WM_HIP(hipEventRecord(e0, s));
+        for (int i = 0; i < iters && rc == WM_OK; ++i)
+            rc = wm_dec_attention(ctx, (const float *)dq, (const bf16_t *)dk + (size_t)(i % n_slices) * slice,
+                                  (const bf16_t *)dv + (size_t)(i % n_slices) * slice, B, H, T, n_keys, nullptr, nsplit,
+                                  (float *)dp, (bf16_t *)datt, true);
+    }
+    WM_HIP(hipEventRecord(e1, s));
+    WM_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    WM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = ms * 1e3f / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    void *fr[] = {dk, dv, dq, dp, datt};
+    for (void *p : fr) (void)hipFree(p);
     return rc;
 }
