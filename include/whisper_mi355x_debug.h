@@ -48,6 +48,9 @@ int wmdbg_bench_dec_gemv(wm_ctx *ctx, int B, int N, int K, int ln, int resid, in
 int wmdbg_bench_dec_attention(wm_ctx *ctx, int B, int H, int T, int n_keys, int nsplit, int n_slices,
                               int iters, float *avg_us);
 
+/* Dependent-launch floor: average microseconds per trivial kernel, eager vs hipGraph replay. */
+int wmdbg_bench_launch_floor(wm_ctx *ctx, int iters, int grid, float *eager_us, float *graph_us);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,9 @@ struct DecGemvDev {
     const bf16_t *W;
     const float *bias;
     const float *x, *ln_g, *ln_b;
+    const float *stats_in;  // DA_LN: [stats_parts][16][2] partial (sum x, sum x^2) per row
+    int stats_parts;
+    float *stats_out;       // DE_RESID: this launch's per-tile partials of the UPDATED residual
     const bf16_t *a_bf16;
     float *out_f32;
     bf16_t *out_bf16;
@@ -98,86 +101,99 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
         wf[u] = __builtin_nontemporal_load((const u32x4 *)(wp + sc * 512));
     }
 
+    // ---- 1b. epilogue operands of wave 0 (bias, old residual, position): requested now so the
+    // kernel has ONE global-memory round trip on its critical path, not one per phase
+    const int n = n0 + nrow;
+    const bool nvalid = n < p.N;
+    const int nc = nvalid ? n : p.N - 1;
+    float bvs = 0.f, xold[4] = {0.f, 0.f, 0.f, 0.f};
+    int pos = 0;
+    if (wave == 0) {  // wave-uniform
+        if (p.bias) bvs = p.bias[nc];
+        if (p.pos_ptr) pos = *p.pos_ptr;
+        if (EPI == DE_RESID) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = kq * 4 + r;
+                xold[r] = p.out_f32[(long)(b < p.B ? b : p.B - 1) * p.ldo + nc];
+            }
+        }
+    }
+
     if (AMODE == DA_LN) {
-        // ---- 2. fused LayerNorm: this wave normalises x[0..B)[kbase .. kbase+KC) ------------
-        // lane owns float4 columns j4 = lane and lane + 64 (KC <= 512); rows in groups of 8;
-        // two-pass fp32 statistics across the workgroup (a row is split over the NW waves).
+        // ---- 2. fused LayerNorm apply: this wave normalises x[0..B)[kbase .. kbase+KC) into its
+        // private LDS tile.  The row statistics were produced by whoever wrote x last (embedding
+        // or a DE_RESID launch) as per-tile partial sums in a FIXED slab order, so summing them
+        // here is deterministic and needs no workgroup barrier or atomics.  Every load of this
+        // prologue (statistics, gamma/beta, 8 activation rows) is issued before the first use.
+        float *st = part + wave * 32;  // [16][2] mean, rstd (wave-private)
+        const int row = lane & 15, grp = lane >> 4;  // 4 lane groups stride over the parts
+        constexpr int SP = 20;                       // parts per lane group: d/16 <= 80 parts
+        float2 sv[SP];
+#pragma unroll
+        for (int u = 0; u < SP; ++u) {
+            const int pc = grp + 4 * u < p.stats_parts ? grp + 4 * u : 0;  // clamped, masked below
+            sv[u] = *(const float2 *)(p.stats_in + ((long)pc * 16 + row) * 2);
+        }
         const int kc4 = p.KC >> 2;
         int j4c[2];
-        float jm[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int j4 = lane + 64 * u;
-            jm[u] = j4 < kc4 ? 1.f : 0.f;
-            j4c[u] = j4 < kc4 ? j4 : kc4 - 1;
-        }
+        for (int u = 0; u < 2; ++u) j4c[u] = lane + 64 * u < kc4 ? lane + 64 * u : kc4 - 1;
         float4 gv[2], bv[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             gv[u] = *(const float4 *)(p.ln_g + kbase + 4 * j4c[u]);
             bv[u] = *(const float4 *)(p.ln_b + kbase + 4 * j4c[u]);
         }
-        for (int b0 = 0; b0 < p.B; b0 += 8) {  // wave-uniform: 1 or 2 trips
-            float4 xv[8][2];
+        float4 xv[8][2];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int bc = b0 + b < p.B ? b0 + b : p.B - 1;
+        for (int b = 0; b < 8; ++b) {
+            const int bc = b < p.B ? b : p.B - 1;
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    xv[b][u] = *(const float4 *)(p.x + (long)bc * p.K + kbase + 4 * j4c[u]);
+            for (int u = 0; u < 2; ++u) xv[b][u] = *(const float4 *)(p.x + (long)bc * p.K + kbase + 4 * j4c[u]);
+        }
+        {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int u = 0; u < SP; ++u) {
+                const float m = grp + 4 * u < p.stats_parts ? 1.f : 0.f;
+                s1 += sv[u].x * m;
+                s2 += sv[u].y * m;
             }
-            // pass 1: row sums
+            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+            const float mean = s1 / (float)p.K;
+            float var = s2 / (float)p.K - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            if (lane < 16) *(float2 *)(st + lane * 2) = make_float2(mean, rsqrtf(var + 1e-5f));
+        }
+        for (int b0 = 0; b0 < p.B; b0 += 8) {  // wave-uniform: 1 trip (B <= 8) or 2
+            if (b0 > 0) {
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                float s = ((xv[b][0].x + xv[b][0].y) + (xv[b][0].z + xv[b][0].w)) * jm[0] +
-                          ((xv[b][1].x + xv[b][1].y) + (xv[b][1].z + xv[b][1].w)) * jm[1];
+                for (int b = 0; b < 8; ++b) {
+                    const int bc = b0 + b < p.B ? b0 + b : p.B - 1;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-                if (lane == 0) part[wave * 16 + b] = s;
-            }
-            __syncthreads();
-            float mean[8];
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                float s = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) s += part[w * 16 + b];
-                mean[b] = s / (float)p.K;
-            }
-            // pass 2: centred second moment
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                float q = 0.f;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const float a0 = xv[b][u].x - mean[b], a1 = xv[b][u].y - mean[b];
-                    const float a2 = xv[b][u].z - mean[b], a3 = xv[b][u].w - mean[b];
-                    q += ((a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3)) * jm[u];
+                    for (int u = 0; u < 2; ++u)
+                        xv[b][u] = *(const float4 *)(p.x + (long)bc * p.K + kbase + 4 * j4c[u]);
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-                if (lane == 0) part[NW * 16 + wave * 16 + b] = q;
             }
-            __syncthreads();
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
-                float q = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) q += part[NW * 16 + w * 16 + b];
-                const float rstd = rsqrtf(q / (float)p.K + 1e-5f);
-                const int br = b0 + b < p.B ? b0 + b : p.B - 1;  // duplicate rows rewrite row B-1 with equal data
+                const int br = b0 + b < p.B ? b0 + b : p.B - 1;  // duplicates rewrite row B-1 with equal data
+                const float2 ms = *(const float2 *)(st + br * 2);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const unsigned lo = pack2((xv[b][u].x - mean[b]) * rstd * gv[u].x + bv[u].x,
-                                              (xv[b][u].y - mean[b]) * rstd * gv[u].y + bv[u].y);
-                    const unsigned hi = pack2((xv[b][u].z - mean[b]) * rstd * gv[u].z + bv[u].z,
-                                              (xv[b][u].w - mean[b]) * rstd * gv[u].w + bv[u].w);
+                    const unsigned lo = pack2((xv[b][u].x - ms.x) * ms.y * gv[u].x + bv[u].x,
+                                              (xv[b][u].y - ms.x) * ms.y * gv[u].y + bv[u].y);
+                    const unsigned hi = pack2((xv[b][u].z - ms.x) * ms.y * gv[u].z + bv[u].z,
+                                              (xv[b][u].w - ms.x) * ms.y * gv[u].w + bv[u].w);
                     // clamped column: lanes past the chunk rewrite column kc4-1 with equal data
                     *(uint2 *)(xs + br * xs_stride + j4c[u] * 8) = make_uint2(lo, hi);
                 }
             }
-            __syncthreads();  // part[] is reused by the next row group
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
     }
 
     // ---- 3. A fragments + MFMA ---------------------------------------------------------------
@@ -229,10 +245,6 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
     }
 
     // ---- epilogue (wave 0): D col n = lane & 15, rows b = kq*4 + r --------------------------
-    const int n = n0 + nrow;
-    const bool nvalid = n < p.N;
-    const float bvs = (nvalid && p.bias) ? p.bias[n] : 0.f;
-    const int pos = p.pos_ptr ? *p.pos_ptr : 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int b = kq * 4 + r;
@@ -250,6 +262,22 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
             if (b < p.B && nvalid && p.out_f32) p.out_f32[(long)b * p.ldo + n] = v;
             continue;
         }
+        if (EPI == DE_RESID) {
+            // residual update + this tile's partial LayerNorm statistics of the updated rows
+            float xn = 0.f;
+            if (b < p.B && nvalid) {
+                xn = xold[r] + v;
+                p.out_f32[(long)b * p.ldo + n] = xn;
+            }
+            float s1 = xn, s2 = xn * xn;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                s1 += __shfl_xor(s1, o);
+                s2 += __shfl_xor(s2, o);
+            }
+            if (p.stats_out && nrow == 0) *(float2 *)(p.stats_out + ((long)blockIdx.x * 16 + b) * 2) = make_float2(s1, s2);
+            continue;
+        }
         if (b >= p.B || !nvalid) continue;
         if (EPI == DE_QKV) {
             const int d = p.N / 3;
@@ -262,8 +290,6 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
             }
         } else if (EPI == DE_Q) {
             p.out_f32[(long)b * p.ldo + n] = v;
-        } else if (EPI == DE_RESID) {
-            p.out_f32[(long)b * p.ldo + n] += v;
         } else if (EPI == DE_GELU) {
             p.out_bf16[(long)b * p.ldo + n] = f2bf(gelu_erf(v));
         }
@@ -271,16 +297,35 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
 }
 
 // ------------------------------------------------------------------ token embedding ------
-// x[b] = token_embedding[seq[pos][b]] + positional_embedding[pos]
+// x[b] = token_embedding[seq[pos][b]] + positional_embedding[pos]  (+ LayerNorm partial statistics)
 __global__ __launch_bounds__(256) void dec_embed_kernel(const int *__restrict__ seq, const int *__restrict__ pos_ptr,
                                                         int B, const bf16_t *__restrict__ emb,
                                                         const float *__restrict__ pemb, int d,
-                                                        float *__restrict__ x) {
+                                                        float *__restrict__ x, float *__restrict__ stats_out) {
+    __shared__ float r1[4], r2[4];
     const int b = blockIdx.x;
     const int pos = *pos_ptr;
     const long tok = seq[pos * B + b];
-    for (int j = threadIdx.x; j < d; j += 256)
-        x[(long)b * d + j] = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)pos * d + j];
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        const float v = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)pos * d + j];
+        x[(long)b * d + j] = v;
+        s1 += v;
+        s2 += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        r1[threadIdx.x >> 6] = s1;
+        r2[threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    // LayerNorm partial statistics of this row: a single part (index 0)
+    if (threadIdx.x == 0 && stats_out)
+        *(float2 *)(stats_out + b * 2) = make_float2((r1[0] + r1[1]) + (r1[2] + r1[3]), (r2[0] + r2[1]) + (r2[2] + r2[3]));
 }
 
 // ------------------------------------------------------------------ single-query attention
@@ -556,9 +601,12 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     const int nw = pick_waves(a.K, a.a_mode == DA_LN);
     WM_REQUIRE(a.K % (32 * nw) == 0 && (a.a_mode != DA_LN || a.K / nw <= 512), WM_ERR_INVALID,
                "dec_gemv: K=%d cannot be split over %d waves", a.K, nw);
+    WM_REQUIRE(a.a_mode != DA_LN || (a.stats_in && a.stats_parts >= 1 && a.stats_parts <= 80), WM_ERR_INVALID,
+               "dec_gemv: LayerNorm mode needs the producer's partial statistics (1..80 parts)");
     DecGemvDev p;
     p.B = a.B; p.N = a.N; p.K = a.K; p.KC = a.K / nw;
     p.W = a.W; p.bias = a.bias; p.x = a.x; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.a_bf16 = a.a_bf16;
+    p.stats_in = a.stats_in; p.stats_parts = a.stats_parts; p.stats_out = a.stats_out;
     p.out_f32 = a.out_f32; p.out_bf16 = a.out_bf16;
     p.kcache = a.kcache; p.vcache = a.vcache; p.pos_ptr = a.pos_ptr; p.n_ctx = a.n_ctx; p.n_head = a.n_head;
     p.ldo = a.ldo; p.tilemax = a.argmax; p.arg_first = a.arg_first; p.arg_last = a.arg_last;
@@ -597,9 +645,9 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
 }
 
 int wm_dec_embed(wm_ctx *ctx, const int *seq, const int *pos_ptr, int B, const bf16_t *emb, const float *pemb,
-                 int d, float *x) {
+                 int d, float *x, float *stats_out) {
     WmProfScope ps(&ctx->prof, "dec_embed", ctx->stream);
-    dec_embed_kernel<<<B, 256, 0, ctx->stream>>>(seq, pos_ptr, B, emb, pemb, d, x);
+    dec_embed_kernel<<<B, 256, 0, ctx->stream>>>(seq, pos_ptr, B, emb, pemb, d, x, stats_out);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }
@@ -652,6 +700,18 @@ int wm_fill_synthetic(wm_ctx *ctx, const WmTensor &t, uint32_t seed, int tensor_
     const int grid = (int)((t.n_elems + 255) / 256 < 16384 ? (t.n_elems + 255) / 256 : 16384);
     synth_fill_kernel<<<grid, 256, 0, ctx->stream>>>(t.ptr, t.is_bf16 ? 1 : 0, t.n_elems, key, scale, t.layout,
                                                      t.conv_c, t.conv_kpad, t.kind);
+    WM_HIP(hipGetLastError());
+    return WM_OK;
+}
+
+// ------------------------------------------------------------------ launch-floor probe -----
+namespace {
+__global__ void trivial_kernel(int *p) {
+    if (p && threadIdx.x == 0 && blockIdx.x == 0) *p = *p + 1;
+}
+}  // namespace
+int wm_launch_trivial(wm_ctx *ctx, int *p, int grid) {
+    trivial_kernel<<<grid, 64, 0, ctx->stream>>>(p);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

@@ -149,6 +149,7 @@ int wm_model_create(wm_ctx *ctx, const wm_dims *dims) {
     WM_TRY(dalloc_t(m, &m->dq, (size_t)WM_DEC_MAXB * d, s));
     WM_TRY(dalloc_t(m, &m->dpart, (size_t)WM_DEC_MAXB * D.n_text_head * WM_MAXSPLIT * 66, s));
     WM_TRY(dalloc_t(m, &m->datt, (size_t)WM_DEC_MAXB * d, s));
+    WM_TRY(dalloc_t(m, &m->dstats, (size_t)(d / 16) * 16 * 2, s));
     WM_TRY(dalloc_t(m, &m->dhid, (size_t)WM_DEC_MAXB * 4 * d, s));
     WM_TRY(dalloc_t(m, &m->dlogits, (size_t)WM_DEC_MAXB * m->vpad, s));
     WM_TRY(dalloc_t(m, &m->dargmax, (size_t)WM_DEC_MAXB * (m->vpad / 16), s));
@@ -413,7 +414,8 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
     const wm_dims &D = m->dims;
     const int d = D.n_text_state, H = D.n_text_head, T = D.n_text_ctx, S = 1500;
     const int ns = wm_dec_attn_splits(B, H);
-    WM_TRY(wm_dec_embed(ctx, m->dseq, m->dpos, B, m->tok_emb, m->dec_pos, d, m->dx));
+    WM_TRY(wm_dec_embed(ctx, m->dseq, m->dpos, B, m->tok_emb, m->dec_pos, d, m->dx, m->dstats));
+    int parts = 1;  // who wrote the residual stream last: embedding (1 part) or a DE_RESID GEMV (d/16 parts)
     for (int l = 0; l < D.n_text_layer; ++l) {
         const DecLayerW &L = m->dec[l];
         bf16_t *kc = m->skv + (size_t)(l * 2 + 0) * B * H * T * 64;
@@ -425,6 +427,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_LN; a.epi = DE_QKV; a.B = B; a.N = 3 * d; a.K = d; a.W = L.wqkv; a.bias = L.bqkv;
         a.x = m->dx; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.out_f32 = m->dq; a.kcache = kc; a.vcache = vc;
+        a.stats_in = m->dstats; a.stats_parts = parts;
         a.pos_ptr = m->dpos; a.n_ctx = T; a.n_head = H;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 2. causal self-attention over positions 0..pos
@@ -432,36 +435,39 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         // 3. out-projection + residual
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_BF16; a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wo; a.bias = L.bo;
-        a.a_bf16 = m->datt; a.out_f32 = m->dx; a.ldo = d;
+        a.a_bf16 = m->datt; a.out_f32 = m->dx; a.ldo = d; a.stats_out = m->dstats;
         WM_TRY(wm_dec_gemv(ctx, a));
+        parts = d / 16;
         // 4. cross_attn_ln + query projection
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_LN; a.epi = DE_Q; a.B = B; a.N = d; a.K = d; a.W = L.wxq; a.bias = L.bxq;
         a.x = m->dx; a.ln_g = L.lnx_g; a.ln_b = L.lnx_b; a.out_f32 = m->dq; a.ldo = d;
+        a.stats_in = m->dstats; a.stats_parts = parts;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 5. cross-attention over the 1500 cached encoder frames
         WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, ns, m->dpart, m->datt, true));
         // 6. out-projection + residual
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_BF16; a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wxo; a.bias = L.bxo;
-        a.a_bf16 = m->datt; a.out_f32 = m->dx; a.ldo = d;
+        a.a_bf16 = m->datt; a.out_f32 = m->dx; a.ldo = d; a.stats_out = m->dstats;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 7. mlp_ln + fc1 + GELU
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_LN; a.epi = DE_GELU; a.B = B; a.N = 4 * d; a.K = d; a.W = L.w1; a.bias = L.b1;
         a.x = m->dx; a.ln_g = L.ln2_g; a.ln_b = L.ln2_b; a.out_bf16 = m->dhid; a.ldo = 4 * d;
+        a.stats_in = m->dstats; a.stats_parts = parts;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 8. fc2 + residual
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_BF16; a.epi = DE_RESID; a.B = B; a.N = d; a.K = 4 * d; a.W = L.w2; a.bias = L.b2;
-        a.a_bf16 = m->dhid; a.out_f32 = m->dx; a.ldo = d;
+        a.a_bf16 = m->dhid; a.out_f32 = m->dx; a.ldo = d; a.stats_out = m->dstats;
         WM_TRY(wm_dec_gemv(ctx, a));
     }
     {   // final LayerNorm + tied-embedding logits + fused per-tile arg-max
         DecGemvArgs a;
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_LN; a.epi = DE_LOGITS; a.B = B; a.N = D.n_vocab; a.K = d; a.W = m->tok_emb;
-        a.x = m->dx; a.ln_g = m->ln_g; a.ln_b = m->ln_b;
+        a.x = m->dx; a.ln_g = m->ln_g; a.ln_b = m->ln_b; a.stats_in = m->dstats; a.stats_parts = parts;
         a.out_f32 = want_logits ? m->dlogits : nullptr; a.ldo = m->vpad;
         a.argmax = m->dargmax; a.arg_first = arg_first; a.arg_last = arg_last;
         WM_TRY(wm_dec_gemv(ctx, a));

@@ -95,6 +95,7 @@ struct WmModel {
     float *dx = nullptr;        // [16][d]   decoder residual stream
     float *dq = nullptr;        // [16][d]   query (self or cross)
     float *dpart = nullptr;     // [16][H][WM_MAXSPLIT][66] attention partials (m, l, o[64])
+    float *dstats = nullptr;    // [d/16][16][2] LayerNorm partial statistics of the residual stream
     bf16_t *datt = nullptr;     // [16][d]   attention head outputs (bf16 A operand of the out-projection)
     bf16_t *dhid = nullptr;     // [16][4d]
     float *dlogits = nullptr;   // [B][vpad]
@@ -180,6 +181,9 @@ struct DecGemvArgs {
     // A operand
     const float *x;        // DA_LN: residual stream [B][K]
     const float *ln_g, *ln_b;
+    const float *stats_in; // DA_LN: [stats_parts][16][2] partial (sum, sum of squares) per row, from the producer of x
+    int stats_parts;
+    float *stats_out;      // DE_RESID: [N/16][16][2] partials of the updated residual (may be null)
     const bf16_t *a_bf16;  // DA_BF16: [B][K]
     // outputs
     float *out_f32;        // DE_Q: [B][N]; DE_RESID: residual [B][N] (+=); DE_LOGITS: [B][ldo]
@@ -194,7 +198,7 @@ struct DecGemvArgs {
 int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a);
 // x[b] = token_embedding[seq[*pos_ptr][b]] + positional_embedding[*pos_ptr]
 int wm_dec_embed(wm_ctx *ctx, const int *seq, const int *pos_ptr, int B, const bf16_t *emb, const float *pemb,
-                 int d, float *x);
+                 int d, float *x, float *stats_out);
 // Single-query attention over a K/V cache [B][H][T_stride][64] -> bf16 head outputs att[B][H*64].
 // Keys 0 .. n-1 with n = *pos_ptr + 1 when pos_ptr != null, else n_keys.
 int wm_dec_attn_splits(int B, int H);

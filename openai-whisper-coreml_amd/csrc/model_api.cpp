@@ -455,9 +455,21 @@ extern "C" int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, co
     memset(&a, 0, sizeof(a));
     a.B = B; a.N = N; a.K = K; a.W = (const bf16_t *)dW; a.bias = (const float *)dbias;
     a.out_f32 = (float *)dout; a.ldo = N; a.epi = DE_Q; a.pos_ptr = nullptr;
+    void *dst = nullptr;
     if (ln_g) {
         WM_TRY(up(&dg, ln_g, (size_t)K * 4, s));
         WM_TRY(up(&db, ln_b, (size_t)K * 4, s));
+        // the producer's partial statistics: here 3 uneven parts computed on the host
+        std::vector<float> st(3 * 16 * 2, 0.f);
+        for (int b = 0; b < B; ++b)
+            for (int k = 0; k < K; ++k) {
+                const int part = k < K / 4 ? 0 : (k < K / 2 ? 1 : 2);
+                const float v = x[(size_t)b * K + k];
+                st[(part * 16 + b) * 2] += v;
+                st[(part * 16 + b) * 2 + 1] += v * v;
+            }
+        WM_TRY(up(&dst, st.data(), st.size() * 4, s));
+        a.stats_in = (const float *)dst; a.stats_parts = 3;
         a.a_mode = DA_LN; a.x = (const float *)dx; a.ln_g = (const float *)dg; a.ln_b = (const float *)db;
     } else {
         to_bf16(x, x16, (size_t)B * K);
@@ -469,7 +481,7 @@ extern "C" int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, co
         WM_HIP(hipMemcpyAsync(out, dout, (size_t)B * N * 4, hipMemcpyDeviceToHost, s));
         WM_HIP(hipStreamSynchronize(s));
     }
-    void *fr[] = {dx, dx16, dg, db, dW, dbias, dout};
+    void *fr[] = {dx, dx16, dg, db, dW, dbias, dout, dst};
     for (void *p : fr)
         if (p) (void)hipFree(p);
     return rc;
@@ -526,7 +538,11 @@ extern "C" int wmdbg_bench_dec_gemv(wm_ctx *ctx, int B, int N, int K, int ln, in
     DecGemvArgs a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.N = N; a.K = K; a.out_f32 = (float *)dout; a.ldo = Npad; a.epi = resid ? DE_RESID : DE_Q;
-    if (ln) { a.a_mode = DA_LN; a.x = (const float *)dx; a.ln_g = (const float *)dg; a.ln_b = (const float *)db; }
+    void *dstat;
+    WM_TRY(up(&dstat, nullptr, (size_t)(K / 16 + 1) * 16 * 2 * 4, s));
+    if (resid) a.stats_out = (float *)dstat;
+    if (ln) { a.a_mode = DA_LN; a.x = (const float *)dx; a.ln_g = (const float *)dg; a.ln_b = (const float *)db;
+              a.stats_in = (const float *)dstat; a.stats_parts = K / 16; }
     else { a.a_mode = DA_BF16; a.a_bf16 = (const bf16_t *)dx16; }
     wm_dec_gemv_set_waves_override(nw_override);
     hipEvent_t e0, e1;
@@ -547,7 +563,7 @@ extern "C" int wmdbg_bench_dec_gemv(wm_ctx *ctx, int B, int N, int K, int ln, in
     WM_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = ms * 1e3f / iters;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    void *fr[] = {dW, dx, dx16, dg, db, dout};
+    void *fr[] = {dW, dx, dx16, dg, db, dout, dstat};
     for (void *p : fr) (void)hipFree(p);
     return rc;
 }
@@ -583,4 +599,42 @@ extern "C" int wmdbg_bench_dec_attention(wm_ctx *ctx, int B, int H, int T, int n
     void *fr[] = {dk, dv, dq, dp, datt};
     for (void *p : fr) (void)hipFree(p);
     return rc;
+}
+
+int wm_launch_trivial(wm_ctx *ctx, int *p, int grid);
+// Dependent-launch floor of this machine: `iters` trivial kernels (each increments one HBM word,
+// so they are truly serialised), eager stream launches vs one captured hipGraph replayed.
+extern "C" int wmdbg_bench_launch_floor(wm_ctx *ctx, int iters, int grid, float *eager_us, float *graph_us) {
+    WM_TRY(wm_ctx_make_current(ctx));
+    hipStream_t s = ctx->stream;
+    void *d;
+    WM_TRY(up(&d, nullptr, 64, s));
+    hipEvent_t e0, e1;
+    WM_HIP(hipEventCreate(&e0));
+    WM_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 20; ++i) WM_TRY(wm_launch_trivial(ctx, (int *)d, grid));
+    WM_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) WM_TRY(wm_launch_trivial(ctx, (int *)d, grid));
+    WM_HIP(hipEventRecord(e1, s));
+    WM_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    WM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *eager_us = ms * 1e3f / iters;
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    WM_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < iters; ++i) (void)wm_launch_trivial(ctx, (int *)d, grid);
+    WM_HIP(hipStreamEndCapture(s, &g));
+    WM_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    WM_HIP(hipGraphLaunch(ge, s));
+    WM_HIP(hipStreamSynchronize(s));
+    WM_HIP(hipEventRecord(e0, s));
+    WM_HIP(hipGraphLaunch(ge, s));
+    WM_HIP(hipEventRecord(e1, s));
+    WM_HIP(hipStreamSynchronize(s));
+    WM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *graph_us = ms * 1e3f / iters;
+    (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
+    return WM_OK;
 }

@@ -5,6 +5,10 @@ import openai_whisper_coreml_amd as pkg
 c = pkg.binding.Context()
 lib = c.lib
 us = ctypes.c_float()
+e_us, g_us = ctypes.c_float(), ctypes.c_float()
+for grid in (1, 256, 1024):
+    lib.wmdbg_bench_launch_floor(c.handle, 500, grid, ctypes.byref(e_us), ctypes.byref(g_us))
+    print('launch floor grid=%d: eager %.2f us/kernel, graph %.2f us/kernel' % (grid, e_us.value, g_us.value))
 def gemv(B, N, K, ln, resid, nw=0, mats=32, iters=320):
     st = lib.wmdbg_bench_dec_gemv(c.handle, B, N, K, ln, resid, mats, iters, nw, ctypes.byref(us))
     gb = N * K * 2 / 1e9
