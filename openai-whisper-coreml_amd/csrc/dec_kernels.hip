@@ -485,35 +485,67 @@ __global__ __launch_bounds__(64) void dec_attn_combine_kernel(const float *__res
 }
 
 // ------------------------------------------------------------------ arg-max -> next token
-// ONE workgroup: reduces the per-tile packed maxima of all B rows, writes the chosen token of
-// row b into the sequence buffer at position pos+1 (when that position is not part of the
-// prompt) and finally advances the device-side position -- the only writer of *pos_ptr.
-__global__ __launch_bounds__(256) void argmax_tokens_kernel(const unsigned long long *__restrict__ tilemax,
-                                                            int n_tiles, int B, int *__restrict__ seq,
-                                                            int *__restrict__ pos_ptr, int n_prompt,
-                                                            int *__restrict__ result, int arg_first) {
-    __shared__ unsigned long long wk[4];
+// ONE workgroup of 16 waves closes a decode step: wave b reduces the per-tile packed maxima of
+// sequence b (all loads in flight at once), the chosen token goes into the sequence buffer at
+// position pos+1 unless that position belongs to the prompt, then the SAME launch embeds the
+// tokens of position pos+1 (token + positional embedding, plus the LayerNorm partial statistics
+// the next layer-0 GEMV expects) and advances the device-side position -- so a step has no
+// separate embedding launch and *pos_ptr has exactly one writer.
+__global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long long *__restrict__ tilemax,
+                                                             int n_tiles, int B, int *__restrict__ seq,
+                                                             int *__restrict__ pos_ptr, int n_prompt,
+                                                             int *__restrict__ result, int arg_first,
+                                                             const bf16_t *__restrict__ emb,
+                                                             const float *__restrict__ pemb, int d, int n_ctx,
+                                                             float *__restrict__ x, float *__restrict__ stats_out) {
+    __shared__ int tok_s[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pos = pos_ptr ? *pos_ptr : 0;
-    for (int b = 0; b < B; ++b) {
+    if (wave < B) {
+        const unsigned long long *row = tilemax + (long)wave * n_tiles;
         unsigned long long key = 0ull;
-        for (int t = threadIdx.x; t < n_tiles; t += 256) {
-            const unsigned long long k = tilemax[(long)b * n_tiles + t];
-            key = k > key ? k : key;
+        for (int t0 = lane; t0 < n_tiles; t0 += 64 * 8) {
+            unsigned long long k[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + 64 * u;
+                k[u] = row[t < n_tiles ? t : t0];  // clamped: duplicates do not change a max
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) key = k[u] > key ? k[u] : key;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned long long ok = __shfl_xor(key, o);
             key = ok > key ? ok : key;
         }
-        if ((threadIdx.x & 63) == 0) wk[threadIdx.x >> 6] = key;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < 4; ++w) key = wk[w] > key ? wk[w] : key;
+        if (lane == 0) {
             const int tok = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
-            if (seq && pos + 1 >= n_prompt) seq[(pos + 1) * B + b] = tok;
-            if (result) result[b] = tok - arg_first;
+            int nxt = tok;
+            if (seq) {
+                if (pos + 1 >= n_prompt) seq[(pos + 1) * B + wave] = tok;
+                else nxt = seq[(pos + 1) * B + wave];
+            }
+            tok_s[wave] = nxt;
+            if (result) result[wave] = tok - arg_first;
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    if (x && wave < B && pos + 1 < n_ctx) {
+        const long tok = tok_s[wave];
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = lane; j < d; j += 64) {
+            const float v = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)(pos + 1) * d + j];
+            x[(long)wave * d + j] = v;
+            s1 += v;
+            s2 += v * v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+        }
+        if (lane == 0 && stats_out) *(float2 *)(stats_out + wave * 2) = make_float2(s1, s2);
     }
     if (threadIdx.x == 0 && pos_ptr) *pos_ptr = pos + 1;
 }
@@ -680,10 +712,12 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
     return WM_OK;
 }
 
-int wm_argmax_reduce(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
-                     int n_prompt, int *result, int arg_first) {
-    WmProfScope ps(&ctx->prof, "argmax_reduce", ctx->stream);
-    argmax_tokens_kernel<<<1, 256, 0, ctx->stream>>>(tilemax, n_tiles, B, seq, pos_ptr, n_prompt, result, arg_first);
+int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
+                    int n_prompt, int *result, int arg_first, const bf16_t *emb, const float *pemb, int d, int n_ctx,
+                    float *x, float *stats_out) {
+    WmProfScope ps(&ctx->prof, "argmax_embed", ctx->stream);
+    argmax_embed_kernel<<<1, 1024, 0, ctx->stream>>>(tilemax, n_tiles, B, seq, pos_ptr, n_prompt, result, arg_first,
+                                                     emb, pemb, d, n_ctx, x, stats_out);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

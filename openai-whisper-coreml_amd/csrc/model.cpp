@@ -414,7 +414,6 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
     const wm_dims &D = m->dims;
     const int d = D.n_text_state, H = D.n_text_head, T = D.n_text_ctx, S = 1500;
     const int ns = wm_dec_attn_splits(B, H);
-    WM_TRY(wm_dec_embed(ctx, m->dseq, m->dpos, B, m->tok_emb, m->dec_pos, d, m->dx, m->dstats));
     int parts = 1;  // who wrote the residual stream last: embedding (1 part) or a DE_RESID GEMV (d/16 parts)
     for (int l = 0; l < D.n_text_layer; ++l) {
         const DecLayerW &L = m->dec[l];
@@ -473,4 +472,16 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         WM_TRY(wm_dec_gemv(ctx, a));
     }
     return WM_OK;
+}
+
+int wm_model_embed_first(wm_ctx *ctx, int B) {
+    WmModel *m = ctx->model;
+    return wm_dec_embed(ctx, m->dseq, m->dpos, B, m->tok_emb, m->dec_pos, m->dims.n_text_state, m->dx, m->dstats);
+}
+
+int wm_model_close_step(wm_ctx *ctx, int B, int n_prompt, bool write_seq, int *result, int arg_first) {
+    WmModel *m = ctx->model;
+    return wm_argmax_embed(ctx, m->dargmax, m->vpad / 16, B, write_seq ? m->dseq : nullptr, m->dpos, n_prompt, result,
+                           arg_first, m->tok_emb, m->dec_pos, m->dims.n_text_state, m->dims.n_text_ctx, m->dx,
+                           m->dstats);
 }

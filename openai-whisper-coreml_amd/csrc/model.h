@@ -126,11 +126,14 @@ int wm_model_encode_dev(wm_ctx *ctx, const float *d_mel, int B, float *d_xa_out 
 int wm_model_cross_kv(wm_ctx *ctx, int B);                 // from m->xn (bf16 encoder output)
 int wm_model_set_xa(wm_ctx *ctx, const float *d_xa, int B);  // f32 xa -> m->xn (bf16)
 int wm_model_decode_begin(wm_ctx *ctx, int B);
-// One decoder position for all B sequences: tokens m->dseq[*dpos][0..B), position *m->dpos
-// (device memory).  Always ends with logits -> per-tile arg-max over [arg_first, arg_last]
-// (m->dargmax); want_logits additionally stores f32 logits [B][vpad] in m->dlogits.  Does NOT
-// advance the position: follow with wm_argmax_reduce (which does).
+// One decoder position for all B sequences, position *m->dpos (device memory).  Expects the
+// embedded input of that position in m->dx (+ m->dstats): wm_model_embed_first for the first
+// position, afterwards produced by wm_model_close_step.  Ends with logits -> per-tile arg-max over
+// [arg_first, arg_last] (m->dargmax); want_logits additionally stores f32 logits in m->dlogits.
 int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, int arg_last);
+int wm_model_embed_first(wm_ctx *ctx, int B);
+// arg-max reduce + write next token (positions >= n_prompt) + embed next position + advance *dpos
+int wm_model_close_step(wm_ctx *ctx, int B, int n_prompt, bool write_seq, int *result, int arg_first);
 int wm_model_set_pos(wm_ctx *ctx, int pos);
 
 // ---------------------------------------------------------------- kernel launchers ----
@@ -205,9 +208,11 @@ int wm_dec_attn_splits(int B, int H);
 int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
                      int T_stride, int n_keys, const int *pos_ptr, int nsplit, float *part, bf16_t *att,
                      bool cross);
-// Reduce the per-tile packed maxima of a DE_LOGITS launch (one workgroup): chosen token of row
-// b -> seq[(*pos_ptr + 1) * B + b] when that position is >= n_prompt; (token - arg_first) ->
-// result[b]; then *pos_ptr += 1.  seq / pos_ptr / result may be null.
-int wm_argmax_reduce(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
-                     int n_prompt, int *result, int arg_first);
+// Close a decode step (one workgroup): reduce the per-tile packed maxima of a DE_LOGITS launch;
+// chosen token of row b -> seq[(*pos_ptr + 1) * B + b] when that position is >= n_prompt;
+// (token - arg_first) -> result[b]; embed the tokens of position *pos_ptr + 1 into x (+ LayerNorm
+// partial statistics) when x != null; then *pos_ptr += 1.  seq / pos_ptr / result / x may be null.
+int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
+                    int n_prompt, int *result, int arg_first, const bf16_t *emb, const float *pemb, int d, int n_ctx,
+                    float *x, float *stats_out);
 int wm_fill_synthetic(wm_ctx *ctx, const WmTensor &t, uint32_t seed, int tensor_id);

@@ -152,6 +152,7 @@ extern "C" int wm_decode_logits(wm_ctx *ctx, const int32_t *tokens, int B, int T
     WM_TRY(load_xa(ctx, xa, B, mem));
     WM_HIP(hipMemcpyAsync(m->dseq, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     WM_TRY(wm_model_set_pos(ctx, 0));
+    WM_TRY(wm_model_embed_first(ctx, B));
     float *d_out = logits;
     char *st = nullptr;
     if (mem == WM_MEM_HOST) {
@@ -170,8 +171,9 @@ extern "C" int wm_decode_logits(wm_ctx *ctx, const int32_t *tokens, int B, int T
             rc = WM_ERR_HIP;
             break;
         }
-        // teacher forcing: keep the given tokens, just advance the device-side position
-        rc = wm_argmax_reduce(ctx, m->dargmax, m->vpad / 16, B, nullptr, m->dpos, T, nullptr, 0);
+        // teacher forcing: every position < T is "prompt", so the given tokens are kept; this
+        // embeds position t+1 and advances the device-side position
+        rc = wm_model_close_step(ctx, B, T, true, nullptr, 0);
     }
     if (rc == WM_OK && mem == WM_MEM_HOST) {
         if (hipMemcpyAsync(logits, d_out, (size_t)B * T * V * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) {
@@ -200,8 +202,10 @@ extern "C" int wm_detect_language(wm_ctx *ctx, const float *xa, int B, int32_t s
     std::vector<int32_t> sots(B, sot);  // Whisper.swift:34-35
     WM_HIP(hipMemcpyAsync(m->dseq, sots.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
     WM_TRY(wm_model_set_pos(ctx, 0));                                       // also fences `sots`
+    WM_TRY(wm_model_embed_first(ctx, B));
     WM_TRY(wm_model_decode_step(ctx, B, false, lang_first, lang_last));     // :36-37
-    WM_TRY(wm_argmax_reduce(ctx, m->dargmax, m->vpad / 16, B, nullptr, nullptr, 0, m->dresult, lang_first));  // :38
+    WM_TRY(wm_argmax_embed(ctx, m->dargmax, m->vpad / 16, B, nullptr, nullptr, 0, m->dresult, lang_first, nullptr,
+                           nullptr, 0, 0, nullptr, nullptr));               // :38
     std::vector<int32_t> res(B);
     WM_HIP(hipMemcpyAsync(res.data(), m->dresult, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));
@@ -266,9 +270,10 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
             for (int b = 0; b < Bg; ++b) pr[(size_t)t * Bg + b] = prompt[t];
         WM_HIP(hipMemcpyAsync(m->dseq, pr.data(), pr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         if ((rc = wm_model_set_pos(ctx, 0)) != WM_OK) break;
+        if ((rc = wm_model_embed_first(ctx, Bg)) != WM_OK) break;
         const int n_steps = n_prompt + max_new - 1;
-        // One decoder position = embed + 8 launches per layer + logits + arg-max (which writes
-        // the next token and advances *dpos).  Nothing in it depends on host state, so it is
+        // One decoder position = 8 launches per layer + logits + arg-max/embed (which writes the
+        // next token, embeds the next position and advances *dpos).  Nothing in it depends on host state, so it is
         // captured ONCE into a hipGraph and replayed for every position.
         static const bool no_graph = getenv("WM_NO_GRAPH") != nullptr;
         const bool use_graph = !no_graph && !ctx->prof.on;
@@ -278,8 +283,7 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
             if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
             WM_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
             int crc = wm_model_decode_step(ctx, Bg, false, 0, D.n_vocab - 1);
-            if (crc == WM_OK)
-                crc = wm_argmax_reduce(ctx, m->dargmax, m->vpad / 16, Bg, m->dseq, m->dpos, n_prompt, nullptr, 0);
+            if (crc == WM_OK) crc = wm_model_close_step(ctx, Bg, n_prompt, true, nullptr, 0);
             hipError_t ce = hipStreamEndCapture(ctx->stream, &m->graph);
             if (crc != WM_OK) { rc = crc; break; }
             WM_HIP(ce);
@@ -291,8 +295,7 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
                 WM_HIP(hipGraphLaunch(m->graph_exec, ctx->stream));
             } else {
                 rc = wm_model_decode_step(ctx, Bg, false, 0, D.n_vocab - 1);
-                if (rc == WM_OK)
-                    rc = wm_argmax_reduce(ctx, m->dargmax, m->vpad / 16, Bg, m->dseq, m->dpos, n_prompt, nullptr, 0);
+                if (rc == WM_OK) rc = wm_model_close_step(ctx, Bg, n_prompt, true, nullptr, 0);
             }
         }
         if (rc != WM_OK) break;
