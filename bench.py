@@ -161,8 +161,10 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl")   # nccl == RCCL on ROCm (xGMI inside a node)
 
+    import importlib
     import openai_whisper_coreml_amd as pkg
     B = pkg.binding
+    sharding = importlib.import_module("openai_whisper_coreml_amd.sharding")
     dims = B.MODEL_DIMS[args.model]
     ctx = B.Context(dims, device=local_rank)
     ctx.init_synthetic(20240928)
@@ -183,10 +185,8 @@ def main():
         toks, lens = ctx.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE,
                                            pcm_dtype=B.WM_I16, B=nb)
         if world > 1:
-            t = torch.from_numpy(np.concatenate([lens[:, None], toks], axis=1)).cuda()
-            out = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(out, t)               # [1 + max_new] int32 per chunk per rank
-            gathered = out
+            # the only exchange of the whole job: one fixed-stride all-gather of the token streams
+            gathered = sharding.gather_tokens(dist, toks, lens, nb * world, world, device="cuda")
         return toks, lens
 
     def sync_all():

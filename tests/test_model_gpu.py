@@ -96,6 +96,22 @@ def test_encoder_parity(tiny):
     assert got.shape == (2, 1500, 128) and e <= ENC_TOL
 
 
+def test_committed_model_golden(pkg):
+    """tests/golden/model_golden.npz (fp32 oracle outputs) vs the HIP path on device-generated weights."""
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "model_golden.npz"))
+    dims = dict(R.TINY_DIMS)
+    ctx = pkg.binding.Context(dims)
+    ctx.init_synthetic(int(g["seed"]))
+    ctx.finalize()
+    mel = g["mel"].astype(np.float32)[None]
+    xa = ctx.encode_mel(mel)
+    assert R.rel_l2(xa[0, g["rows"]], g["xa_rows"]) <= ENC_TOL
+    lg = ctx.decode_logits(g["tokens"][None], xa)
+    assert R.rel_l2(lg[0][:, :64], g["logits_head"]) <= 2 * LOGIT_TOL
+    ctx.close()
+
+
 def test_encoder_batch_independence(tiny):
     dims, _, _, ctx = tiny
     _, mel = mels(ctx, 3)
@@ -235,3 +251,18 @@ def test_error_paths(pkg):
     fe.close()
     with pytest.raises(pkg.binding.WhisperError):
         pkg.binding.Context(dict(dims, n_audio_state=100))
+
+
+def test_cpp_host_harness_mirrors_the_swift_flow(pkg):
+    """host/lid_main.cpp dlopens the .so and runs ContentView.swift:56-63 -> Whisper.swift:23-40."""
+    import subprocess
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("_b", os.path.join(ROOT, "openai-whisper-coreml_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    exe = b.build_host()
+    r = subprocess.run([exe, pkg.binding.LIB_PATH, "base", "synthetic:3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] in pkg.Whisper.LANGUAGES and float(lines[1]) > 0

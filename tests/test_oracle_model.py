@@ -1,0 +1,104 @@
+"""CPU tests that anchor the model oracle (oracle/whisper_ref.py).  The reference pins nothing
+at boundary #2 ("parity unpinned": openai-whisper / CoreML are un-vendored, no weights, no
+tests), so the restatement is cross-checked against the INDEPENDENT Whisper implementation in
+`transformers`, against its own KV-cached path, and against committed golden vectors."""
+import importlib
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN
+from oracle import whisper_ref as R
+
+W = importlib.import_module("openai_whisper_coreml_amd.weights")
+
+
+def _sd(seed):
+    sd = W.synthetic_state_dict(dict(R.TINY_DIMS), seed)
+    rng = np.random.default_rng(seed)
+    for k in sd:
+        if "ln" in k and k.endswith("weight"):
+            sd[k] = (1 + 0.1 * rng.standard_normal(sd[k].shape)).astype(np.float32)
+        if "ln" in k and k.endswith("bias"):
+            sd[k] = (0.1 * rng.standard_normal(sd[k].shape)).astype(np.float32)
+    return sd
+
+
+def test_against_transformers_whisper():
+    from transformers import WhisperConfig, WhisperModel
+    dims = dict(R.TINY_DIMS)
+    sd_np = _sd(3)
+    sd = R.to_torch(sd_np)
+    cfg = WhisperConfig(vocab_size=dims["n_vocab"], num_mel_bins=80, encoder_layers=2, encoder_attention_heads=2,
+                        decoder_layers=2, decoder_attention_heads=2, decoder_ffn_dim=512, encoder_ffn_dim=512,
+                        d_model=128, max_source_positions=1500, max_target_positions=448,
+                        activation_function="gelu", dropout=0.0, attention_dropout=0.0, activation_dropout=0.0,
+                        scale_embedding=False, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                        decoder_start_token_id=3)
+    m = WhisperModel(cfg).eval()
+    hf = W.openai_to_hf_state_dict(sd_np)
+    msd = m.state_dict()
+    assert not [k for k in msd if "model." + k not in hf], "key mapping incomplete"
+    m.load_state_dict({k: torch.from_numpy(hf["model." + k]) for k in msd})
+    rng = np.random.default_rng(0)
+    mel = torch.from_numpy(rng.standard_normal((2, 80, 3000)).astype(np.float32) * 0.5)
+    toks = torch.tensor([[5, 9, 100, 7], [3, 3, 900, 12]])
+    with torch.no_grad():
+        out = m(input_features=mel, decoder_input_ids=toks)
+    xa = R.encode(sd, dims, mel)
+    assert R.rel_l2(xa.numpy(), out.encoder_last_hidden_state.numpy()) < 1e-5
+    lg = R.decode_logits(sd, dims, toks.numpy(), xa).numpy()
+    lg_hf = (out.last_hidden_state @ torch.from_numpy(hf["model.decoder.embed_tokens.weight"]).T).numpy()
+    assert R.rel_l2(lg, lg_hf) < 1e-5
+    # and the HF -> openai key mapping is the exact inverse
+    back = {W.hf_to_openai_key(k): v for k, v in hf.items()}
+    assert set(back) == set(sd_np) and all(np.array_equal(back[k], sd_np[k]) for k in sd_np)
+
+
+def test_kv_cached_greedy_equals_full_recompute():
+    dims = dict(R.TINY_DIMS)
+    sd = R.to_torch(_sd(4))
+    mel = np.random.default_rng(1).standard_normal((1, 80, 3000)).astype(np.float32) * 0.5
+    xa = R.encode(sd, dims, mel)
+    toks, lens, step_logits = R.greedy(sd, dims, xa, [1, 2], 5)
+    full = np.concatenate([[1, 2], toks[0][:4]])[None]
+    ref = R.decode_logits(sd, dims, full, xa).numpy()
+    assert np.abs(step_logits[0] - ref[0, 1:]).max() < 1e-5 and lens[0] == 5
+    idx, conf = R.detect_language(sd, dims, xa, sot=10, lang_first=20, lang_last=118)
+    assert conf.shape == (1, 99) and idx[0] == int(conf[0].argmax())
+
+
+def test_model_golden_vectors():
+    """Committed fixture (tests/golden/make_model_golden.py): pins the oracle against drift."""
+    g = np.load(os.path.join(GOLDEN, "model_golden.npz"))
+    dims = dict(R.TINY_DIMS)
+    sd = R.to_torch(W.synthetic_state_dict(dims, int(g["seed"])))
+    xa = R.encode(sd, dims, g["mel"][None])
+    assert np.abs(xa.numpy()[0, g["rows"]] - g["xa_rows"]).max() < 2e-5
+    lg = R.decode_logits(sd, dims, g["tokens"][None], xa).numpy()[0]
+    assert np.abs(lg[:, :64] - g["logits_head"]).max() < 2e-5
+    assert abs(float(lg.sum()) - float(g["logits_sum"])) < 1e-2
+
+
+def test_synthetic_weights_are_deterministic_and_bf16_exact():
+    dims = dict(R.TINY_DIMS)
+    a, b = W.synthetic_state_dict(dims, 9), W.synthetic_state_dict(dims, 9)
+    c = W.synthetic_state_dict(dims, 10)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert not np.array_equal(a["decoder.token_embedding.weight"], c["decoder.token_embedding.weight"])
+    w = a["encoder.blocks.0.mlp.0.weight"]
+    assert np.array_equal(W.bf16_round_f32(w), w) and abs(float(w.std()) - 0.02) < 2e-3
+    assert np.array_equal(a["encoder.positional_embedding"], W.sinusoids(1500, 128))
+    names = [n for n, _, _ in W.tensor_specs(dims)]
+    assert len(names) == len(set(names)) and "decoder.blocks.1.cross_attn.key.weight" in names
+    assert "decoder.blocks.1.cross_attn.key.bias" not in names      # openai-whisper: key has no bias
+
+
+def test_flat_weight_file_roundtrip(tmp_path):
+    dims = dict(R.TINY_DIMS)
+    sd = W.synthetic_state_dict(dims, 2)
+    p = os.path.join(tmp_path, "w.wm")
+    W.save_flat(p, dims, sd)
+    d2, sd2 = W.load_flat(p)
+    assert d2 == dims and set(sd2) == set(sd) and all(np.array_equal(sd[k], sd2[k]) for k in sd)
