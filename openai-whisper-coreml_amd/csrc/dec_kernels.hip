@@ -331,22 +331,27 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int *__restrict__ 
 // ------------------------------------------------------------------ single-query attention
 // grid (B*H, nsplit), 1024 threads = 16 waves.  Keys [start, end) of this split; 8 lanes share
 // one 128-byte K/V row (16 B each), a wave covers 8 rows per load, the 16 waves 128 rows; every
-// lane keeps ATT_UNR loads in flight (16 waves x 4 KiB = 64 KiB per CU) so a CU streams its
-// (sequence, head) cache slice at HBM rate.  nsplit == 1: writes the normalised head output
+// lane requests all of its rows up front so a CU streams its (sequence, head) cache slice at HBM
+// rate.  nsplit == 1: writes the normalised head output
 // as bf16 (the out-projection's A operand); nsplit > 1: writes (m, l, o[64]) partials for
 // dec_attn_combine_kernel.
-constexpr int ATT_UNR = 4;
 constexpr int ATT_NW = 16;
 constexpr int ATT_MAXK = 1536;
 
+// NIT = ceil(max keys per workgroup / 128): 12 covers the 1500 encoder frames, 4 the 448-token
+// self-attention cache.  Every K row a lane needs is requested in ONE batch, the V rows are
+// requested as soon as the scores are out of the K registers (they do not depend on the softmax),
+// so the kernel has two overlapped memory rounds instead of 2*NIT/4 serialised ones; scores and
+// probabilities stay in registers (no LDS pass over them), two workgroup barriers in total.
+template <int NIT>
 __global__ __launch_bounds__(1024) void dec_attn_kernel(const float *__restrict__ q,
                                                         const bf16_t *__restrict__ kc,
                                                         const bf16_t *__restrict__ vc, int H, int d,
                                                         int T_stride, int n_keys_const,
                                                         const int *__restrict__ pos_ptr, int nsplit,
                                                         float *__restrict__ part, bf16_t *__restrict__ att) {
-    __shared__ float sc[ATT_MAXK];
     __shared__ float wred[ATT_NW];
+    __shared__ float wl[ATT_NW];
     __shared__ float wacc[ATT_NW][64];
     const int bh = blockIdx.x, b = bh / H, h = bh % H, sp = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -358,44 +363,48 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const float *__restrict_
     int end = start + chunk;
     if (end > n_keys) end = n_keys;
     const int cnt = end > start ? end - start : 0;
+    const int last = cnt > 0 ? cnt - 1 : 0;
+    const bf16_t *kb = kc + ((long)bh * T_stride + start) * 64 + e8 * 8;
+    const bf16_t *vb = vc + ((long)bh * T_stride + start) * 64 + e8 * 8;
 
+    // ---- K rows: one batch of loads -------------------------------------------------------
+    u32x4 kv[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+        int i = u * (ATT_NW * 8) + wave * 8 + rg;
+        i = i < cnt ? i : last;  // clamped: unconditional load
+        kv[u] = *(const u32x4 *)(kb + (long)i * 64);
+    }
     float qe[8];
     {
         const float *qp = q + (long)b * d + h * 64 + e8 * 8;
 #pragma unroll
         for (int i = 0; i < 8; ++i) qe[i] = qp[i] * 0.125f;  // hd^-0.5 (== hd^-0.25 on q and on k)
     }
-    const bf16_t *kb = kc + ((long)bh * T_stride + start) * 64 + e8 * 8;
-    const bf16_t *vb = vc + ((long)bh * T_stride + start) * 64 + e8 * 8;
-    const int last = cnt > 0 ? cnt - 1 : 0;
-
-    // ---- scores ---------------------------------------------------------------------------
+    float sc[NIT];
     float mloc = -1e30f;
-    for (int i0 = wave * 8; i0 < cnt; i0 += ATT_NW * 8 * ATT_UNR) {
-        u32x4 kv[ATT_UNR];
 #pragma unroll
-        for (int u = 0; u < ATT_UNR; ++u) {
-            int i = i0 + u * ATT_NW * 8 + rg;
-            i = i < cnt ? i : last;  // clamped: unconditional load
-            kv[u] = *(const u32x4 *)(kb + (long)i * 64);
+    for (int u = 0; u < NIT; ++u) {
+        const int i = u * (ATT_NW * 8) + wave * 8 + rg;
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a += qe[2 * j] * __uint_as_float(kv[u][j] << 16);
+            a += qe[2 * j + 1] * __uint_as_float(kv[u][j] & 0xffff0000u);
         }
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        a += __shfl_xor(a, 4);
+        sc[u] = i < cnt ? a : -1e30f;
+        mloc = fmaxf(mloc, sc[u]);
+    }
+    // ---- V rows requested now: in flight during the max reduction and the exponentials -------
+    u32x4 vv[NIT];
 #pragma unroll
-        for (int u = 0; u < ATT_UNR; ++u) {
-            const int i = i0 + u * ATT_NW * 8 + rg;
-            float a = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a += qe[2 * j] * __uint_as_float(kv[u][j] << 16);
-                a += qe[2 * j + 1] * __uint_as_float(kv[u][j] & 0xffff0000u);
-            }
-            a += __shfl_xor(a, 1);
-            a += __shfl_xor(a, 2);
-            a += __shfl_xor(a, 4);
-            if (i < cnt) {
-                if (e8 == 0) sc[i] = a;
-                mloc = fmaxf(mloc, a);
-            }
-        }
+    for (int u = 0; u < NIT; ++u) {
+        int i = u * (ATT_NW * 8) + wave * 8 + rg;
+        i = i < cnt ? i : last;
+        vv[u] = *(const u32x4 *)(vb + (long)i * 64);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, o));
@@ -404,40 +413,17 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const float *__restrict_
     float M = wred[0];
 #pragma unroll
     for (int w = 1; w < ATT_NW; ++w) M = fmaxf(M, wred[w]);
-    __syncthreads();
-    // ---- exp + sum ------------------------------------------------------------------------
-    float lloc = 0.f;
-    for (int i = tid; i < cnt; i += ATT_NW * 64) {
-        const float pv = __expf(sc[i] - M);
-        sc[i] = pv;
-        lloc += pv;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) lloc += __shfl_xor(lloc, o);
-    if (lane == 0) wred[wave] = lloc;
-    __syncthreads();
-    float L = 0.f;
-#pragma unroll
-    for (int w = 0; w < ATT_NW; ++w) L += wred[w];
-    // ---- o = sum_i p_i V[i] -----------------------------------------------------------------
+    // ---- p = exp(s - M), o = sum_i p_i V[i] ---------------------------------------------------
     float oa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i0 = wave * 8; i0 < cnt; i0 += ATT_NW * 8 * ATT_UNR) {
-        u32x4 vv[ATT_UNR];
+    float lloc = 0.f;
 #pragma unroll
-        for (int u = 0; u < ATT_UNR; ++u) {
-            int i = i0 + u * ATT_NW * 8 + rg;
-            i = i < cnt ? i : last;
-            vv[u] = *(const u32x4 *)(vb + (long)i * 64);
-        }
+    for (int u = 0; u < NIT; ++u) {
+        const float pv = sc[u] > -1e29f ? __expf(sc[u] - M) : 0.f;
+        lloc += pv;  // every one of the 8 lanes of a row holds the same pv: counted once below
 #pragma unroll
-        for (int u = 0; u < ATT_UNR; ++u) {
-            const int i = i0 + u * ATT_NW * 8 + rg;
-            const float pv = i < cnt ? sc[i] : 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                oa[2 * j] += pv * __uint_as_float(vv[u][j] << 16);
-                oa[2 * j + 1] += pv * __uint_as_float(vv[u][j] & 0xffff0000u);
-            }
+        for (int j = 0; j < 4; ++j) {
+            oa[2 * j] += pv * __uint_as_float(vv[u][j] << 16);
+            oa[2 * j + 1] += pv * __uint_as_float(vv[u][j] & 0xffff0000u);
         }
     }
 #pragma unroll
@@ -446,15 +432,22 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const float *__restrict_
         oa[i] += __shfl_xor(oa[i], 16);
         oa[i] += __shfl_xor(oa[i], 32);
     }
+    lloc += __shfl_xor(lloc, 8);
+    lloc += __shfl_xor(lloc, 16);
+    lloc += __shfl_xor(lloc, 32);
     if (rg == 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) wacc[wave][e8 * 8 + i] = oa[i];
+        if (e8 == 0) wl[wave] = lloc;
     }
     __syncthreads();
     if (tid < 64) {
-        float o = 0.f;
+        float o = 0.f, L = 0.f;
 #pragma unroll
-        for (int w = 0; w < ATT_NW; ++w) o += wacc[w][tid];
+        for (int w = 0; w < ATT_NW; ++w) {
+            o += wacc[w][tid];
+            L += wl[w];
+        }
         if (nsplit == 1) {
             att[(long)b * d + h * 64 + tid] = f2bf(o / L);
         } else {
@@ -700,8 +693,14 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
     {
         WmProfScope ps(&ctx->prof, cross ? "dec_attn_cross" : "dec_attn_self", ctx->stream);
         dim3 grid(B * H, nsplit);
-        dec_attn_kernel<<<grid, 1024, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, nsplit,
-                                                       part, att);
+        const int max_keys = pos_ptr ? T_stride : n_keys;
+        const int per_wg = ((max_keys + nsplit - 1) / nsplit + 7) & ~7;
+        if (per_wg <= 4 * ATT_NW * 8)
+            dec_attn_kernel<4><<<grid, 1024, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, nsplit,
+                                                              part, att);
+        else
+            dec_attn_kernel<12><<<grid, 1024, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, nsplit,
+                                                               part, att);
         WM_HIP(hipGetLastError());
     }
     if (nsplit > 1) {
