@@ -155,11 +155,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("WM_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl")   # nccl == RCCL on ROCm (xGMI inside a node)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
 
     import importlib
     import openai_whisper_coreml_amd as pkg
@@ -184,13 +185,13 @@ def main():
         nonlocal gathered
         toks, lens = ctx.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE,
                                            pcm_dtype=B.WM_I16, B=nb)
-        if world > 1:
+        if use_dist:
             # the only exchange of the whole job: one fixed-stride all-gather of the token streams
             gathered = sharding.gather_tokens(dist, toks, lens, nb * world, world, device="cuda")
         return toks, lens
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
         ctx.sync()
@@ -205,7 +206,7 @@ def main():
         stage += ctx.last_stage_ms()
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64).cuda()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -220,20 +221,34 @@ def main():
             ctx.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE, pcm_dtype=B.WM_I16, B=nb)
         prof = ctx.profile()
         ctx.profile_enable(False)
+        ev_over = ctx.profile_overhead_us()      # cost of the two hipEventRecord calls themselves
+        traffic_db = {}
+        try:
+            traffic_db = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        except Exception:
+            pass
         if prof:
             dom = max(prof, key=lambda k: prof[k]["ms"])
             kind, work = algorithmic_work(dom, dims, nb)
-            avg_s = prof[dom]["ms"] / prof[dom]["n"] * 1e-3
+            raw_us = prof[dom]["ms"] / prof[dom]["n"] * 1e3
+            avg_s = max(raw_us - ev_over, 1e-3) * 1e-6
+            # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE pass (profiles/), only
+            # valid for the geometry it was taken on (large-v2, B = 8)
+            traffic = None
+            if args.model == "large-v2" and nb == 8 and dom in traffic_db:
+                traffic = traffic_db[dom]["hbm_read_bytes_per_launch"]
             if kind == "hbm":
                 ach = work / avg_s / 1e9
                 roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_us": avg_s * 1e6,
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_us": avg_s * 1e6,
+                        "avg_us_events_raw": raw_us, "event_overhead_us": ev_over,
                         "alg_bytes_per_launch": work, "launches": prof[dom]["n"]}
             elif kind == "mfma":
                 ach = work / avg_s / 1e12
                 roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TF,
-                        "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TF, "traffic": None,
-                        "avg_us": avg_s * 1e6, "alg_flops_per_launch": work, "launches": prof[dom]["n"]}
+                        "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TF, "traffic": traffic,
+                        "avg_us": avg_s * 1e6, "avg_us_events_raw": raw_us, "event_overhead_us": ev_over,
+                        "alg_flops_per_launch": work, "launches": prof[dom]["n"]}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -266,12 +281,12 @@ def main():
             "decoder_ms_per_step": stage_s[2] * 1e3 / dec_steps,
             "stage_ms": {"frontend": stage_s[0] * 1e3, "encoder_xkv": stage_s[1] * 1e3, "decode": stage_s[2] * 1e3},
             "roofline": roof,
-            "roofline_note": "per-launch HIP events (hipEventRecord on the launch stream) in a second pass of the same steps",
+            "roofline_note": "mean launch duration from per-launch HIP events (hipEventRecord on the launch stream) in a second pass of the same steps, minus the measured cost of an empty event pair; traffic = 2 x FETCH_SIZE from a separate rocprofv3 --pmc pass (profiles/)",
             "cpu_baseline": cpu,
             "kernel_families": fams,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     ctx.close()
 

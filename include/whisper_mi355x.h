@@ -157,6 +157,9 @@ int wm_sync(wm_ctx *ctx);
  * totals are read back with wm_profile_get (which synchronises). */
 int wm_profile_enable(wm_ctx *ctx, int on);
 int wm_profile_reset(wm_ctx *ctx);
+/* Mean cost (microseconds) of an EMPTY event-bracketed scope on the launch stream: subtract it from
+ * a family's mean launch duration. */
+int wm_profile_overhead_us(wm_ctx *ctx, float *us);
 /* Writes a JSON object {"family": {"ms": total_ms, "n": launches}, ...} into buf. */
 int wm_profile_json(wm_ctx *ctx, char *buf, size_t buf_bytes);
 /* Wall-clock stage split of the last wm_transcribe_greedy call, in ms (HIP events):

@@ -104,6 +104,7 @@ def load_library(path=None):
         "wm_profile_enable": [vp, ip],
         "wm_profile_reset": [vp],
         "wm_profile_json": [vp, ctypes.c_char_p, sz],
+        "wm_profile_overhead_us": [vp, vp],
         "wm_last_stage_ms": [vp, vp],
     }
     for name, args in sigs.items():
@@ -230,6 +231,11 @@ class Context:
         buf = ctypes.create_string_buffer(1 << 16)
         _check(self.lib, self.lib.wm_profile_json(self.handle, buf, len(buf)))
         return json.loads(buf.value.decode())
+
+    def profile_overhead_us(self):
+        v = ctypes.c_float()
+        _check(self.lib, self.lib.wm_profile_overhead_us(self.handle, ctypes.byref(v)))
+        return float(v.value)
 
     def last_stage_ms(self):
         out = np.zeros(3, dtype=np.float32)

@@ -9,6 +9,7 @@
 
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "wm_internal.h"
 #include "model.h"
@@ -199,6 +200,30 @@ extern "C" int wm_profile_json(wm_ctx *ctx, char *buf, size_t n) {
     s += "}";
     WM_REQUIRE(s.size() + 1 <= n, WM_ERR_INVALID, "buffer too small (%zu needed)", s.size() + 1);
     memcpy(buf, s.c_str(), s.size() + 1);
+    return WM_OK;
+}
+// Cost of the measurement itself: mean elapsed time between the two hipEventRecord calls of an
+// EMPTY profiler scope on the launch stream (subtract it from a family's mean launch duration).
+extern "C" int wm_profile_overhead_us(wm_ctx *ctx, float *us) {
+    WM_TRY(wm_ctx_make_current(ctx));
+    WM_REQUIRE(us, WM_ERR_INVALID, "null pointer");
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    const int n = 256;
+    std::vector<hipEvent_t> ev(2 * n);
+    for (auto &e : ev) WM_HIP(hipEventCreate(&e));
+    for (int i = 0; i < n; ++i) {
+        WM_HIP(hipEventRecord(ev[2 * i], ctx->stream));
+        WM_HIP(hipEventRecord(ev[2 * i + 1], ctx->stream));
+    }
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    double tot = 0;
+    for (int i = 0; i < n; ++i) {
+        float ms = 0.f;
+        WM_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+        tot += ms;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    *us = (float)(tot * 1e3 / n);
     return WM_OK;
 }
 extern "C" int wm_last_stage_ms(wm_ctx *ctx, float out3[3]) {

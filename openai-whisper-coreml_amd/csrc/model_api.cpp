@@ -552,12 +552,21 @@ extern "C" int wmdbg_bench_dec_gemv(wm_ctx *ctx, int B, int N, int K, int ln, in
     WM_HIP(hipEventCreate(&e0));
     WM_HIP(hipEventCreate(&e1));
     int rc = WM_OK;
-    for (int pass = 0; pass < 2 && rc == WM_OK; ++pass) {
-        if (pass == 1) WM_HIP(hipEventRecord(e0, s));
-        for (int i = 0; i < iters && rc == WM_OK; ++i) {
-            a.W = (const bf16_t *)dW + (size_t)(i % n_mats) * Npad * K;
-            rc = wm_dec_gemv(ctx, a);
-        }
+    // capture the launch chain once, replay it: per-kernel time = true serialized duration
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    WM_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    for (int i = 0; i < iters && rc == WM_OK; ++i) {
+        a.W = (const bf16_t *)dW + (size_t)(i % n_mats) * Npad * K;
+        rc = wm_dec_gemv(ctx, a);
+    }
+    WM_HIP(hipStreamEndCapture(s, &g));
+    if (rc == WM_OK) {
+        WM_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        WM_HIP(hipGraphLaunch(ge, s));
+        WM_HIP(hipStreamSynchronize(s));
+        WM_HIP(hipEventRecord(e0, s));
+        WM_HIP(hipGraphLaunch(ge, s));
     }
     wm_dec_gemv_set_waves_override(0);
     WM_HIP(hipEventRecord(e1, s));
@@ -566,6 +575,8 @@ extern "C" int wmdbg_bench_dec_gemv(wm_ctx *ctx, int B, int N, int K, int ln, in
     WM_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = ms * 1e3f / iters;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ge) (void)hipGraphExecDestroy(ge);
+    if (g) (void)hipGraphDestroy(g);
     void *fr[] = {dW, dx, dx16, dg, db, dout, dstat};
     for (void *p : fr) (void)hipFree(p);
     return rc;

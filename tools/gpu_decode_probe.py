@@ -16,8 +16,9 @@ def gemv(B, N, K, ln, resid, nw=0, mats=32, iters=320):
 for (name, N, K, ln, resid) in [("ln_qkv", 3840, 1280, 1, 0), ("attn_out", 1280, 1280, 0, 1), ("ln_q", 1280, 1280, 1, 0),
                                 ("ln_fc1", 5120, 1280, 1, 0), ("fc2", 1280, 5120, 0, 1), ("logits", 51865, 1280, 1, 0)]:
     line = "%-9s N=%5d K=%4d:" % (name, N, K)
-    for nw in ([0, 1, 2, 4] if ln else [0, 2, 4, 8, 16]):
-        line += "  nw=%d %s |" % (nw, gemv(8, N, K, ln, resid, nw, mats=(4 if N > 10000 else 32), iters=(40 if N > 10000 else 320)))
+    for mats in (1, 2, 4, 64):
+        if N > 10000 and mats > 4: continue
+        line += "  mats=%d %s |" % (mats, gemv(8, N, K, ln, resid, 0, mats=mats, iters=(40 if N > 10000 else 320)))
     print(line)
 def attn(B, H, T, nk, ns, slices=8, iters=160):
     st = lib.wmdbg_bench_dec_attention(c.handle, B, H, T, nk, ns, slices, iters, ctypes.byref(us))
