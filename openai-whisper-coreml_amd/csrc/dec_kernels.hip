@@ -18,6 +18,8 @@
 //     keys (small batches) with a combine kernel.
 //   * the decode position lives in HBM (*pos_ptr) and is advanced by the arg-max kernel, so
 //     ONE captured hipGraph of the whole step replays for every position.
+#include <stdlib.h>
+
 #include "model.h"
 
 namespace {
@@ -62,7 +64,30 @@ struct DecGemvDev {
     unsigned long long *tilemax;  // [B][n_tiles] (DE_LOGITS)
     int n_tiles;
     int arg_first, arg_last;
+    const char *pf_ptr;   // next GEMV's weights: extra workgroups pull them into this XCD's L2
+    long pf_tile_bytes;  // bytes of one 16-row weight tile of that matrix
+    int pf_tiles;
 };
+
+// L2 warm-up workgroup: blockIdx >= n_tiles of the compute grid.  Workgroup n_tiles + t reads tile t of
+// the NEXT launch's weight matrix.  Dispatch places block b on XCD b % 8 (observed, not guaranteed --
+// a wrong guess only costs speed) and n_tiles % 8 == 0, so tile t lands in the L2 of the XCD whose
+// workgroup t will consume it; L2 contents survive the kernel boundary (measured: a GEMV whose
+// weights are L2-resident is 0.7-2.0 us shorter).  Runs on CUs the skinny GEMV leaves idle.
+__device__ __forceinline__ void l2_warm_tile(const char *base, long tile_bytes, int tile, int nthreads) {
+    const u32x4 *src = (const u32x4 *)(base + (long)tile * tile_bytes);
+    const long n16 = tile_bytes >> 4;
+    for (long i = threadIdx.x; i < n16; i += (long)nthreads * 8) {
+        u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long j = i + (long)u * nthreads;
+            v[u] = src[j < n16 ? j : i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) asm volatile("" ::"v"(v[u]));
+    }
+}
 
 // Weight stream of one wave: WG_MAX k-steps are issued up front, unconditionally (steps past
 // the wave's range re-read its last fragment: an L1 hit, no HBM traffic), BEFORE the LayerNorm
@@ -77,6 +102,10 @@ constexpr int WG_MAX = 12;
 template <int AMODE, int EPI, int NW>
 __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x >= p.n_tiles) {  // workgroup-uniform
+        l2_warm_tile(p.pf_ptr, p.pf_tile_bytes, (int)blockIdx.x - p.n_tiles, NW * 64);
+        return;
+    }
     float *red = (float *)smem;
     float *part = red + NW * 256;
     char *xs_all = (char *)(part + 2 * NW * 16);
@@ -349,7 +378,12 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const float *__restrict_
                                                         const bf16_t *__restrict__ vc, int H, int d,
                                                         int T_stride, int n_keys_const,
                                                         const int *__restrict__ pos_ptr, int nsplit,
-                                                        float *__restrict__ part, bf16_t *__restrict__ att) {
+                                                        float *__restrict__ part, bf16_t *__restrict__ att,
+                                                        int n_bh, const char *pf_ptr, long pf_tile_bytes) {
+    if ((int)blockIdx.x >= n_bh) {  // L2 warm-up workgroup for the next GEMV's weights (see l2_warm_tile)
+        l2_warm_tile(pf_ptr, pf_tile_bytes, (int)blockIdx.x - n_bh, 1024);
+        return;
+    }
     __shared__ float wred[ATT_NW];
     __shared__ float wl[ATT_NW];
     __shared__ float wacc[ATT_NW][64];
@@ -373,7 +407,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const float *__restrict_
     for (int u = 0; u < NIT; ++u) {
         int i = u * (ATT_NW * 8) + wave * 8 + rg;
         i = i < cnt ? i : last;  // clamped: unconditional load
-        kv[u] = *(const u32x4 *)(kb + (long)i * 64);
+        kv[u] = __builtin_nontemporal_load((const u32x4 *)(kb + (long)i * 64));
     }
     float qe[8];
     {
@@ -404,7 +438,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const float *__restrict_
     for (int u = 0; u < NIT; ++u) {
         int i = u * (ATT_NW * 8) + wave * 8 + rg;
         i = i < cnt ? i : last;
-        vv[u] = *(const u32x4 *)(vb + (long)i * 64);
+        vv[u] = __builtin_nontemporal_load((const u32x4 *)(vb + (long)i * 64));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, o));
@@ -635,8 +669,16 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     p.out_f32 = a.out_f32; p.out_bf16 = a.out_bf16;
     p.kcache = a.kcache; p.vcache = a.vcache; p.pos_ptr = a.pos_ptr; p.n_ctx = a.n_ctx; p.n_head = a.n_head;
     p.ldo = a.ldo; p.tilemax = a.argmax; p.arg_first = a.arg_first; p.arg_last = a.arg_last;
-    const int grid = (a.N + 15) / 16;
+    int grid = (a.N + 15) / 16;
     p.n_tiles = grid;
+    static const bool no_pf = getenv("WM_NO_PREFETCH") != nullptr;
+    p.pf_ptr = nullptr; p.pf_tile_bytes = 0; p.pf_tiles = 0;
+    if (!no_pf && a.pf_ptr && a.pf_rows >= 16 && grid % 8 == 0) {
+        p.pf_ptr = (const char *)a.pf_ptr;
+        p.pf_tile_bytes = 16L * a.pf_k * 2;
+        p.pf_tiles = a.pf_rows / 16;
+        grid += p.pf_tiles;
+    }
     const int key = a.a_mode * 8 + a.epi;
     switch (key) {
         case DA_LN * 8 + DE_QKV: {
@@ -686,21 +728,28 @@ int wm_dec_attn_splits(int B, int H) {
 
 int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
                      int T_stride, int n_keys, const int *pos_ptr, int nsplit, float *part, bf16_t *att,
-                     bool cross) {
+                     bool cross, const bf16_t *pf_ptr, int pf_rows, int pf_k) {
     WM_REQUIRE(nsplit >= 1 && nsplit <= 8, WM_ERR_INVALID, "dec_attention: nsplit %d out of range", nsplit);
     WM_REQUIRE(T_stride <= ATT_MAXK && n_keys <= ATT_MAXK, WM_ERR_INVALID,
                "dec_attention: more than %d keys", ATT_MAXK);
     {
         WmProfScope ps(&ctx->prof, cross ? "dec_attn_cross" : "dec_attn_self", ctx->stream);
-        dim3 grid(B * H, nsplit);
+        static const bool no_pf = getenv("WM_NO_PREFETCH") != nullptr;
+        int gx = B * H;
+        long tile_bytes = 0;
+        if (!no_pf && pf_ptr && nsplit == 1 && gx % 8 == 0 && pf_rows >= 16) {
+            tile_bytes = 16L * pf_k * 2;
+            gx += pf_rows / 16;
+        }
+        dim3 grid(gx, nsplit);
         const int max_keys = pos_ptr ? T_stride : n_keys;
         const int per_wg = ((max_keys + nsplit - 1) / nsplit + 7) & ~7;
         if (per_wg <= 4 * ATT_NW * 8)
             dec_attn_kernel<4><<<grid, 1024, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, nsplit,
-                                                              part, att);
+                                                              part, att, B * H, (const char *)pf_ptr, tile_bytes);
         else
             dec_attn_kernel<12><<<grid, 1024, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, nsplit,
-                                                               part, att);
+                                                               part, att, B * H, (const char *)pf_ptr, tile_bytes);
         WM_HIP(hipGetLastError());
     }
     if (nsplit > 1) {

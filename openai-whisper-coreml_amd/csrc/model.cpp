@@ -430,11 +430,12 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.pos_ptr = m->dpos; a.n_ctx = T; a.n_head = H;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 2. causal self-attention over positions 0..pos
-        WM_TRY(wm_dec_attention(ctx, m->dq, kc, vc, B, H, T, 0, m->dpos, ns, m->dpart, m->datt, false));
+        WM_TRY(wm_dec_attention(ctx, m->dq, kc, vc, B, H, T, 0, m->dpos, ns, m->dpart, m->datt, false, L.wo, d, d));
         // 3. out-projection + residual
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_BF16; a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wo; a.bias = L.bo;
         a.a_bf16 = m->datt; a.out_f32 = m->dx; a.ldo = d; a.stats_out = m->dstats;
+        a.pf_ptr = L.wxq; a.pf_rows = d; a.pf_k = d;
         WM_TRY(wm_dec_gemv(ctx, a));
         parts = d / 16;
         // 4. cross_attn_ln + query projection
@@ -444,22 +445,25 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.stats_in = m->dstats; a.stats_parts = parts;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 5. cross-attention over the 1500 cached encoder frames
-        WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, ns, m->dpart, m->datt, true));
+        WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, ns, m->dpart, m->datt, true, L.wxo, d, d));
         // 6. out-projection + residual
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_BF16; a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wxo; a.bias = L.bxo;
         a.a_bf16 = m->datt; a.out_f32 = m->dx; a.ldo = d; a.stats_out = m->dstats;
+        a.pf_ptr = L.w1; a.pf_rows = 4 * d; a.pf_k = d;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 7. mlp_ln + fc1 + GELU
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_LN; a.epi = DE_GELU; a.B = B; a.N = 4 * d; a.K = d; a.W = L.w1; a.bias = L.b1;
         a.x = m->dx; a.ln_g = L.ln2_g; a.ln_b = L.ln2_b; a.out_bf16 = m->dhid; a.ldo = 4 * d;
         a.stats_in = m->dstats; a.stats_parts = parts;
+        a.pf_ptr = L.w2; a.pf_rows = d; a.pf_k = 4 * d;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 8. fc2 + residual
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_BF16; a.epi = DE_RESID; a.B = B; a.N = d; a.K = 4 * d; a.W = L.w2; a.bias = L.b2;
         a.a_bf16 = m->dhid; a.out_f32 = m->dx; a.ldo = d; a.stats_out = m->dstats;
+        if (l + 1 < D.n_text_layer) { a.pf_ptr = m->dec[l + 1].wqkv; a.pf_rows = 3 * d; a.pf_k = d; }
         WM_TRY(wm_dec_gemv(ctx, a));
     }
     {   // final LayerNorm + tied-embedding logits + fused per-tile arg-max

@@ -197,6 +197,9 @@ struct DecGemvArgs {
     long ldo;
     unsigned long long *argmax;  // DE_LOGITS: per-tile packed maxima [B][ceil(N/16)] over [arg_first, arg_last]
     int arg_first, arg_last;
+    // optional L2 warm-up of the NEXT skinny GEMV's weights ([pf_rows][pf_k] bf16, WL_TILED)
+    const bf16_t *pf_ptr;
+    int pf_rows, pf_k;
 };
 int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a);
 // x[b] = token_embedding[seq[*pos_ptr][b]] + positional_embedding[*pos_ptr]
@@ -207,7 +210,7 @@ int wm_dec_embed(wm_ctx *ctx, const int *seq, const int *pos_ptr, int B, const b
 int wm_dec_attn_splits(int B, int H);
 int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
                      int T_stride, int n_keys, const int *pos_ptr, int nsplit, float *part, bf16_t *att,
-                     bool cross);
+                     bool cross, const bf16_t *pf_ptr = nullptr, int pf_rows = 0, int pf_k = 0);
 // Close a decode step (one workgroup): reduce the per-tile packed maxima of a DE_LOGITS launch;
 // chosen token of row b -> seq[(*pos_ptr + 1) * B + b] when that position is >= n_prompt;
 // (token - arg_first) -> result[b]; embed the tokens of position *pos_ptr + 1 into x (+ LayerNorm
