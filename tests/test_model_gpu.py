@@ -266,3 +266,63 @@ def test_cpp_host_harness_mirrors_the_swift_flow(pkg):
     assert r.returncode == 0, r.stderr
     lines = r.stdout.strip().splitlines()
     assert lines[0] in pkg.Whisper.LANGUAGES and float(lines[1]) > 0
+
+
+def test_base_geometry_batch32(pkg):
+    """BASELINE.json configs[2]: base multilingual, batch 32 (encoder in one pass, decode in groups of 16)."""
+    dims = pkg.binding.MODEL_DIMS["base"]
+    ctx = pkg.binding.Context(dims)
+    ctx.init_synthetic(3)
+    ctx.finalize()
+    pcm = np.stack([L.synth_chunk(i % 4) for i in range(32)])
+    mel = ctx.logmel(pcm)
+    xa = ctx.encode_mel(mel)
+    assert xa.shape == (32, 1500, 512)
+    assert np.array_equal(xa[0], xa[4]) and np.array_equal(xa[1], xa[29])      # equal chunks -> equal rows
+    sd = R.to_torch({n: ctx.get_tensor(n, s) for n, s, _ in W.tensor_specs(dims)})
+    want = R.encode(sd, dims, mel[:2]).numpy()
+    assert R.rel_l2(xa[:2], want) <= ENC_TOL
+    toks, lens = ctx.transcribe_greedy(pcm, [50258, 50259, 50359, 50363], 4)
+    assert toks.shape == (32, 4) and np.array_equal(toks[0], toks[4]) and np.array_equal(toks[17], toks[21])
+    ctx.close()
+
+
+def test_large_v3_front_end_and_vocabulary(pkg):
+    """BASELINE.json configs[4] geometry, depth cut to 2+2 layers so the oracle stays fast: 128 mel
+    bins (conv1 K = 384), vocabulary 51866, 100 language ids 50259...50358."""
+    dims = dict(pkg.binding.MODEL_DIMS["large-v3"], n_audio_layer=2, n_text_layer=2)
+    ctx = pkg.binding.Context(dims)
+    ctx.init_synthetic(5)
+    ctx.finalize()
+    pcm = np.stack([L.synth_chunk(11), L.synth_chunk(12)])
+    mel = ctx.logmel(pcm, n_mels=128)
+    assert mel.shape == (2, 128, 3000)
+    sd = R.to_torch({n: ctx.get_tensor(n, s) for n, s, _ in W.tensor_specs(dims)})
+    xa = ctx.encode_mel(mel)
+    want = R.encode(sd, dims, mel).numpy()
+    e = R.rel_l2(xa, want)
+    print("large-v3 (2 layers) encoder rel-L2", e)
+    assert e <= ENC_TOL
+    got = ctx.detect_language(want, sot=50258, lang_first=50259, lang_last=50358)
+    _, conf = R.detect_language(sd, dims, want, sot=50258, lang_first=50259, lang_last=50358)
+    assert conf.shape == (2, 100)
+    for b in range(2):
+        _check_choice(conf[b], int(got[b]))
+    toks, _ = ctx.transcribe_greedy(pcm, [50258, 50259, 50360, 50364], 3)
+    assert toks.shape == (2, 3) and toks.max() < 51866
+    ctx.close()
+
+
+def test_wav_to_tokens_pipeline(pkg, tiny, tmp_path):
+    """8f rank 1: WAV (int16 RIFF) -> 30 s chunks -> greedy tokens, equal to feeding the chunks directly."""
+    import importlib
+    A = importlib.import_module("openai_whisper_coreml_amd.audio")
+    dims, _, _, ctx = tiny
+    x = np.concatenate([np.round(L.synth_chunk(1) * 32767), np.round(L.synth_chunk(2)[:100000] * 32767)]).astype(np.int16)
+    p = os.path.join(tmp_path, "rec.wav")
+    A.write_wav_int16(p, x)
+    chunks = A.wav_to_chunks(p)
+    assert chunks.shape == (2, 480000)
+    toks, lens = A.transcribe_chunks(ctx, chunks, [10, 21], 5)
+    direct, _ = ctx.transcribe_greedy(chunks, [10, 21], 5)
+    assert np.array_equal(toks, direct) and lens.tolist() == [5, 5]

@@ -68,3 +68,22 @@ def test_token_allgather_world2_gloo():
         want_l = np.array([(i % 6) + 1 for i in range(n_chunks)], np.int32)
         for _, t, l in res:
             assert np.array_equal(t, want_t) and np.array_equal(l, want_l)
+
+
+def test_wav_reader_roundtrip(tmp_path):
+    A = importlib.import_module("openai_whisper_coreml_amd.audio")
+    x = (np.sin(np.arange(16000 * 31) * 0.01) * 12000).astype(np.int16)        # 31 s -> 2 windows
+    p = os.path.join(tmp_path, "query.wav")
+    A.write_wav_int16(p, x)
+    assert np.array_equal(A.read_wav_int16(p), x)
+    c = A.wav_to_chunks(p)
+    assert c.shape == (2, 480000) and c.dtype == np.int16 and np.array_equal(c[0], x[:480000])
+    assert np.array_equal(c[1, :16000], x[480000:]) and not c[1, 16000:].any()
+    import wave
+    with wave.open(os.path.join(tmp_path, "bad.wav"), "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000); w.writeframes(b"\0" * 8)
+    try:
+        A.read_wav_int16(os.path.join(tmp_path, "bad.wav"))
+        assert False
+    except ValueError:
+        pass
