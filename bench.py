@@ -287,6 +287,7 @@ def main():
         }
         print(json.dumps(line))
     if use_dist:
+        dist.barrier()   # rank 0 ran the instrumented pass / CPU baseline: leave together
         dist.destroy_process_group()
     ctx.close()
 

@@ -51,6 +51,10 @@ int wmdbg_bench_dec_attention(wm_ctx *ctx, int B, int H, int T, int n_keys, int 
 /* Dependent-launch floor: average microseconds per trivial kernel, eager vs hipGraph replay. */
 int wmdbg_bench_launch_floor(wm_ctx *ctx, int iters, int grid, float *eager_us, float *graph_us);
 
+/* Wall time (us) of one replay of a captured graph with ONE chain of `iters` spinning kernels vs TWO
+ * independent chains: tells whether hipGraph runs parallel branches concurrently on this runtime. */
+int wmdbg_bench_graph_branches(wm_ctx *ctx, int iters, int grid, int us_each, float *one_us, float *two_us);
+
 #ifdef __cplusplus
 }
 #endif

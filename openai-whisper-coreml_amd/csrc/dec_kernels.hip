@@ -797,3 +797,16 @@ int wm_launch_trivial(wm_ctx *ctx, int *p, int grid) {
     WM_HIP(hipGetLastError());
     return WM_OK;
 }
+
+// ------------------------------------------------------------------ concurrency probe -------
+namespace {
+__global__ void spin_kernel(int *p, int cycles) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(2);
+    if (p && threadIdx.x == 0 && blockIdx.x == 0) *p = *p + 1;
+}
+}  // namespace
+int wm_launch_spin(hipStream_t s, int *p, int grid, int cycles) {
+    spin_kernel<<<grid, 256, 0, s>>>(p, cycles);
+    return hipGetLastError() == hipSuccess ? WM_OK : WM_ERR_HIP;
+}

@@ -652,3 +652,44 @@ extern "C" int wmdbg_bench_launch_floor(wm_ctx *ctx, int iters, int grid, float 
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
     return WM_OK;
 }
+
+int wm_launch_spin(hipStream_t s, int *p, int grid, int cycles);
+// Do two independent branches of a captured hipGraph run concurrently?  Each branch is a chain of
+// `iters` kernels that spin ~`us_each` microseconds on `grid` workgroups.  Returns wall time of one
+// replay with 1 branch and with 2 branches.
+extern "C" int wmdbg_bench_graph_branches(wm_ctx *ctx, int iters, int grid, int us_each, float *one_us, float *two_us) {
+    WM_TRY(wm_ctx_make_current(ctx));
+    hipStream_t s = ctx->stream, s2;
+    WM_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    void *d;
+    WM_TRY(up(&d, nullptr, 256, s));
+    const int cycles = us_each * 100;  // wall_clock64 ticks at 100 MHz
+    hipEvent_t e0, e1, ef, ej;
+    WM_HIP(hipEventCreate(&e0)); WM_HIP(hipEventCreate(&e1));
+    WM_HIP(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); WM_HIP(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+    for (int nb = 1; nb <= 2; ++nb) {
+        hipGraph_t g; hipGraphExec_t ge;
+        WM_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        if (nb == 2) { WM_HIP(hipEventRecord(ef, s)); WM_HIP(hipStreamWaitEvent(s2, ef, 0)); }
+        for (int i = 0; i < iters; ++i) {
+            WM_TRY(wm_launch_spin(s, (int *)d, grid, cycles));
+            if (nb == 2) WM_TRY(wm_launch_spin(s2, (int *)d + 16, grid, cycles));
+        }
+        if (nb == 2) { WM_HIP(hipEventRecord(ej, s2)); WM_HIP(hipStreamWaitEvent(s, ej, 0)); }
+        WM_HIP(hipStreamEndCapture(s, &g));
+        WM_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        WM_HIP(hipGraphLaunch(ge, s));
+        WM_HIP(hipStreamSynchronize(s));
+        WM_HIP(hipEventRecord(e0, s));
+        WM_HIP(hipGraphLaunch(ge, s));
+        WM_HIP(hipEventRecord(e1, s));
+        WM_HIP(hipStreamSynchronize(s));
+        float ms = 0.f;
+        WM_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *(nb == 1 ? one_us : two_us) = ms * 1e3f;
+        (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(ef); (void)hipEventDestroy(ej);
+    (void)hipStreamDestroy(s2); (void)hipFree(d);
+    return WM_OK;
+}
