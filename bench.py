@@ -258,6 +258,31 @@ def main():
             cpu = {"value": None, "unit": "audio-sec/s", "cores": os.cpu_count(), "kind": "port",
                    "sample": "failed: %r" % (e,)}
 
+    def stage_rooflines(stage_s, dec_steps):
+        """Per-stage algorithmic work (SURVEY.md 8d formulas, per GPU per step) against the roofline that
+        bounds the stage: front end and decode = HBM bytes, encoder + cross-K/V = bf16 MFMA flops."""
+        d, L, V, H = dims["n_text_state"], dims["n_text_layer"], dims["n_vocab"], dims["n_text_head"]
+        da, La, nm = dims["n_audio_state"], dims["n_audio_layer"], dims["n_mels"]
+        fe_bytes = nb * (480000 * 2 + nm * 3000 * 4)
+        enc_flops = nb * (2.0 * 3000 * da * nm * 3 + 2.0 * 1500 * da * da * 3
+                          + La * (8.0 * 1500 * da * da + 4.0 * 1500 * 1500 * da + 16.0 * 1500 * da * da))
+        xkv_flops = nb * L * 4.0 * 1500 * d * d
+        t_mean = (len(prompt) + max_new) / 2.0
+        dec_bytes = dec_steps * (2.0 * (L * 14 * d * d + V * d) + nb * L * 2 * 1500 * d * 2 + nb * L * 2 * t_mean * d * 2)
+        out = {}
+        if stage_s[0] > 0:
+            a = fe_bytes / stage_s[0] / 1e9
+            out["frontend"] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS}
+        if stage_s[1] > 0:
+            a = (enc_flops + xkv_flops) / stage_s[1] / 1e12
+            out["encoder_xkv"] = {"bound": "mfma", "achieved": a, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                                  "frac": a / MFMA_BF16_PEAK_TF}
+        if stage_s[2] > 0:
+            a = dec_bytes / stage_s[2] / 1e9
+            out["decode"] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                             "bytes_per_position": dec_bytes / dec_steps}
+        return out
+
     if rank == 0:
         total_audio = 30.0 * nb * world * args.steps
         dec_steps = len(prompt) + max_new - 1
@@ -281,6 +306,7 @@ def main():
             "decoder_ms_per_step": stage_s[2] * 1e3 / dec_steps,
             "stage_ms": {"frontend": stage_s[0] * 1e3, "encoder_xkv": stage_s[1] * 1e3, "decode": stage_s[2] * 1e3},
             "roofline": roof,
+            "stage_roofline": stage_rooflines(stage_s, dec_steps),
             "roofline_note": "mean launch duration from per-launch HIP events (hipEventRecord on the launch stream) in a second pass of the same steps, minus the measured cost of an empty event pair; traffic = 2 x FETCH_SIZE from a separate rocprofv3 --pmc pass (profiles/)",
             "cpu_baseline": cpu,
             "kernel_families": fams,

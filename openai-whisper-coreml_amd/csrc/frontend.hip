@@ -14,13 +14,16 @@
 // Kernel 1 (logmel_stage1): one workgroup owns FPB = 16*WPB consecutive frames of one
 // chunk.  The PCM span those frames cover is staged ONCE in LDS (coalesced HBM reads,
 // every sample read from HBM once per workgroup instead of 2.5x), with the reflect pad
-// done by index arithmetic.  The DFT uses the window symmetry w[n] == w[400-n], w[0]==0:
-//     Re X[k] =  sum_{n=1..200} w[n] (x[n] + x[400-n]) cos(2 pi k n/400)   (n=200 once)
-//     Im X[k] = -sum_{n=1..199} w[n] (x[n] - x[400-n]) sin(2 pi k n/400)
-// i.e. two [16 frames x 200] x [200 x 208] products per wave, issued on the matrix
-// pipe with the exact-f32 / f64 MFMA (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64:
-// an fmaf chain, no reduced precision), A operand built on the fly from the LDS span, B
-// operand = the L2-resident twiddle table.  Power -> LDS -> banded mel (the filterbank is
+// done by index arithmetic.  The DFT uses two symmetries.  Window: w[n] == w[400-n], w[0]==0:
+//     Re X[k] =  sum_{n=1..200} e[n] cos(2 pi k n/400),  e[n] = w[n] (x[n] + x[400-n])  (n=200 once)
+//     Im X[k] = -sum_{n=1..199} o[n] sin(2 pi k n/400),  o[n] = w[n] (x[n] - x[400-n])
+// Bin pairs: cos(2 pi (200-k) n/400) = (-1)^n cos(2 pi k n/400), sin(..) = -(-1)^n sin(..), so with the
+// sums split over even and odd n (Ce, Co, Se, So) bins k and 200-k come from the SAME four sums:
+//     X[k] = (Ce+Co) - i(Se+So),   X[200-k] = (Ce-Co) - i(So-Se),   k = 0..100.
+// That is four [16 frames x 100] x [100 x 101] products per wave (a quarter of the naive DFT's
+// multiply-adds), issued on the matrix pipe with the exact-f32 / f64 MFMA (v_mfma_f32_16x16x4_f32 /
+// v_mfma_f64_16x16x4_f64: an fmaf chain, no reduced precision); A operand built on the fly from the
+// LDS span, B operand = the L2-resident twiddle tables.  Power -> LDS -> banded mel (the filterbank is
 // 97.6% zeros; summing the non-zero band in ascending k equals the reference's dense
 // ascending-k sum exactly) -> log10 -> store + per-chunk atomic max.
 // Kernel 2 (logmel_stage2): dynamic-range clamp + affine, in place.
@@ -33,8 +36,9 @@
 
 namespace {
 
-constexpr int NJT = 13;          // 13 * 16 = 208 >= 201 bins
+constexpr int NJT = 7;           // 7 * 16 = 112 >= 101 paired bins (k = 0..100)
 constexpr int TW_COLS = NJT * 16;
+constexpr int TW_ROWS = 100;     // even n = 2..200 / odd n = 1..199
 constexpr int PW_STRIDE = 209;   // odd stride: conflict-free column walks
 
 template <typename T>
@@ -94,15 +98,18 @@ __device__ __forceinline__ int span_addr(int frame, int n) { return frame * 161 
 
 template <typename T, int WPB>
 __global__ __launch_bounds__(WPB * 64) void logmel_stage1(
-    const void *__restrict__ pcm, int pcm_dtype, int n_mels, const T *__restrict__ cosT,
-    const T *__restrict__ sinT, const T *__restrict__ win, const int *__restrict__ band_start,
+    const void *__restrict__ pcm, int pcm_dtype, int n_mels, const T *__restrict__ tw,
+    const T *__restrict__ /*unused*/, const T *__restrict__ win, const int *__restrict__ band_start,
     const int *__restrict__ band_len, const float *__restrict__ band_w, T *__restrict__ out,
     unsigned long long *__restrict__ gmax, int blocks_per_chunk) {
     constexpr int FPB = 16 * WPB;
     constexpr int SPAN = (FPB - 1) * WM_HOP + WM_N_FFT;
     constexpr int SPAN_LDS = SPAN + SPAN / 160 + 4;
-    __shared__ T xs[SPAN_LDS];
-    __shared__ T pw[WPB][16][PW_STRIDE];
+    constexpr int PW_LDS = WPB * 16 * PW_STRIDE;
+    // one LDS region: the PCM span during the DFT, the power spectrum afterwards
+    __shared__ T smem[SPAN_LDS > PW_LDS ? SPAN_LDS : PW_LDS];
+    T *xs = smem;
+    T(*pw)[16][PW_STRIDE] = (T(*)[16][PW_STRIDE])smem;
 
     const int chunk = blockIdx.x / blocks_per_chunk;
     const int f0 = (blockIdx.x % blocks_per_chunk) * FPB;
@@ -123,37 +130,51 @@ __global__ __launch_bounds__(WPB * 64) void logmel_stage1(
 
     // ---- DFT of 16 frames per wave on the matrix pipe ------------------------------------
     typedef typename Acc<T>::type acc_t;
-    acc_t accC[NJT], accS[NJT];
+    acc_t acc[4][NJT];  // Ce, Co, Se, So
 #pragma unroll
-    for (int j = 0; j < NJT; ++j) {
-        accC[j] = (acc_t){0, 0, 0, 0};
-        accS[j] = (acc_t){0, 0, 0, 0};
-    }
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < NJT; ++j) acc[t][j] = (acc_t){0, 0, 0, 0};
     const int fr = wave * 16 + (lane & 15);  // A row: frame within the block
     const int kq = lane >> 4;                // A col / B row within the 4-deep k step
     const int col = lane & 15;
-    for (int kk = 0; kk < 50; ++kk) {
-        const int n = 1 + 4 * kk + kq;  // 1..200
-        const T x1 = xs[span_addr(fr, n)];
-        const T x2 = xs[span_addr(fr, WM_N_FFT - n)];
-        const T w = win[n];
-        const T a_c = w * ((n == 200) ? x1 : (x1 + x2));
-        const T a_s = w * (x1 - x2);
-        const T *crow = cosT + (size_t)(n - 1) * TW_COLS + col;
-        const T *srow = sinT + (size_t)(n - 1) * TW_COLS + col;
+    for (int kk = 0; kk < TW_ROWS / 4; ++kk) {
+        const int ie = 4 * kk + kq;          // table row 0..99
+        const int ne = 2 * (ie + 1);         // even n: 2..200
+        const int no = 2 * ie + 1;           // odd n: 1..199
+        const T x1e = xs[span_addr(fr, ne)], x2e = xs[span_addr(fr, WM_N_FFT - ne)];
+        const T x1o = xs[span_addr(fr, no)], x2o = xs[span_addr(fr, WM_N_FFT - no)];
+        const T we = win[ne], wo = win[no];
+        const T a_ce = we * ((ne == 200) ? x1e : (x1e + x2e));
+        const T a_se = we * (x1e - x2e);
+        const T a_co = wo * (x1o + x2o);
+        const T a_so = wo * (x1o - x2o);
+        const T *row = tw + (size_t)ie * TW_COLS + col;
 #pragma unroll
         for (int j = 0; j < NJT; ++j) {
-            accC[j] = mfma4(a_c, crow[j * 16], accC[j]);
-            accS[j] = mfma4(a_s, srow[j * 16], accS[j]);
+            acc[0][j] = mfma4(a_ce, row[0 * TW_ROWS * TW_COLS + j * 16], acc[0][j]);
+            acc[1][j] = mfma4(a_co, row[1 * TW_ROWS * TW_COLS + j * 16], acc[1][j]);
+            acc[2][j] = mfma4(a_se, row[2 * TW_ROWS * TW_COLS + j * 16], acc[2][j]);
+            acc[3][j] = mfma4(a_so, row[3 * TW_ROWS * TW_COLS + j * 16], acc[3][j]);
         }
     }
-    // power (lib.rs:54) -> LDS, [frame][bin]
+    __syncthreads();  // every wave is done with the PCM span: its LDS becomes the power spectrum
+    // power (lib.rs:54) -> LDS, [frame][bin]; bins k and 200-k from the same four sums
 #pragma unroll
     for (int j = 0; j < NJT; ++j) {
+        const int k = j * 16 + col;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const T re = accC[j][r], im = accS[j][r];
-            pw[wave][acc_row(T(0), lane, r)][j * 16 + col] = re * re + im * im;
+            const T ce = acc[0][j][r], co = acc[1][j][r], se = acc[2][j][r], so = acc[3][j][r];
+            const int row = acc_row(T(0), lane, r);
+            if (k <= 100) {
+                const T re = ce + co, im = se + so;
+                pw[wave][row][k] = re * re + im * im;
+            }
+            if (k < 100) {
+                const T re = ce - co, im = so - se;
+                pw[wave][row][200 - k] = re * re + im * im;
+            }
         }
     }
     __syncthreads();
@@ -275,7 +296,9 @@ static int build_bands(const float *filt, int n_mels, int **d_start, int **d_len
 int wm_frontend_init(WmFrontend *fe, hipStream_t stream) {
     if (fe->ready) return WM_OK;
     const double PI = 3.14159265358979323846264338327950288;
-    std::vector<double> c64((size_t)200 * TW_COLS, 0.0), s64((size_t)200 * TW_COLS, 0.0), w64(401);
+    // four tables [cosE | cosO | sinE | sinO], each [100 rows][TW_COLS]: row i of the even tables is
+    // n = 2(i+1), of the odd tables n = 2i+1; column k = 0..100
+    std::vector<double> c64((size_t)4 * TW_ROWS * TW_COLS, 0.0), s64(1, 0.0), w64(401);
     // exact argument reduction: angle index (k*n) mod 400, table of 400 f64 values
     std::vector<double> ct(400), stb(400);
     for (int t = 0; t < 400; ++t) {
@@ -284,11 +307,13 @@ int wm_frontend_init(WmFrontend *fe, hipStream_t stream) {
     }
     // exact zeros / ones where the angle is a multiple of pi/2
     ct[100] = 0.0; ct[300] = 0.0; stb[0] = 0.0; stb[200] = 0.0;
-    for (int n = 1; n <= 200; ++n)
-        for (int k = 0; k < WM_N_BINS; ++k) {
-            const int t = (n * k) % 400;
-            c64[(size_t)(n - 1) * TW_COLS + k] = ct[t];
-            s64[(size_t)(n - 1) * TW_COLS + k] = stb[t];
+    for (int i = 0; i < TW_ROWS; ++i)
+        for (int k = 0; k <= 100; ++k) {
+            const int te = (2 * (i + 1) * k) % 400, to = ((2 * i + 1) * k) % 400;
+            c64[((size_t)0 * TW_ROWS + i) * TW_COLS + k] = ct[te];
+            c64[((size_t)1 * TW_ROWS + i) * TW_COLS + k] = ct[to];
+            c64[((size_t)2 * TW_ROWS + i) * TW_COLS + k] = stb[te];
+            c64[((size_t)3 * TW_ROWS + i) * TW_COLS + k] = stb[to];
         }
     for (int i = 0; i <= 400; ++i) w64[i] = (1.0 - cos(((double)i * 2.0 * PI) / 400.0)) / 2.0;  // lib.rs:26
     std::vector<float> c32(c64.begin(), c64.end()), s32(s64.begin(), s64.end()),
