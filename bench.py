@@ -5,7 +5,9 @@ geometry, 30 s chunks, batch 8 per GPU (BASELINE.json configs[3]), chunk-paralle
 One "step" = one pass of the hot path over one batch of synthetic 16 kHz audio that is
 already resident in HBM (int16 PCM): log-mel front end -> encoder -> cross-attention K/V
 -> KV-cached greedy decode of 224 tokens (n_text_ctx // 2, EOT suppressed so the work is
-fixed) -> tokens on the host.  Everything runs through the C ABI of libwhisper_mi355x.so
+fixed) -> tokens on the host.  Steps are independent batches; --inflight S (default 3) of them
+are kept in flight per GPU on S weight-sharing contexts (the decode chain of one batch is
+latency-bound); the single-batch latency is reported next to the pipelined throughput.  Everything runs through the C ABI of libwhisper_mi355x.so
 (no torch compute; torch is only used for torch.distributed / RCCL at N > 1).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--model large-v2] [--batch 8]
@@ -142,11 +144,13 @@ def cpu_baseline(ctx, dims, pcm16_chunk, prompt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large-v2")
     ap.add_argument("--batch", type=int, default=8, help="30 s chunks per GPU per step")
     ap.add_argument("--new-tokens", type=int, default=224)
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="independent batches kept in flight per GPU (each on its own HIP stream / context clone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -179,31 +183,60 @@ def main():
     prompt = [sot, sot + 1, sot + 101, sot + 105] if dims["n_vocab"] >= 51865 else [50257, 50362]
     max_new = args.new_tokens
 
+    # S independent batches in flight per GPU: the decode chain of ONE batch is latency-bound (258
+    # dependent launches per position), so consecutive steps (= independent batches) are software-
+    # pipelined over S contexts that share the weights and own a HIP stream + KV caches each.
+    import queue
+    import threading
+    S = max(1, args.inflight)
+    ctxs = [ctx] + [ctx.clone() for _ in range(S - 1)]
     gathered = None
 
-    def step():
+    def run_steps(n_steps):
+        """n_steps batches of nb chunks, S in flight; returns summed stage ms of all steps."""
         nonlocal gathered
-        toks, lens = ctx.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE,
-                                           pcm_dtype=B.WM_I16, B=nb)
-        if use_dist:
-            # the only exchange of the whole job: one fixed-stride all-gather of the token streams
-            gathered = sharding.gather_tokens(dist, toks, lens, nb * world, world, device="cuda")
-        return toks, lens
+        todo = queue.Queue()
+        done = queue.Queue()
+        for i in range(n_steps):
+            todo.put(i)
+        stage_sum = np.zeros(3)
+        lock = threading.Lock()
+
+        def worker(c):
+            while True:
+                try:
+                    todo.get_nowait()
+                except queue.Empty:
+                    return
+                toks, lens = c.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE,
+                                                 pcm_dtype=B.WM_I16, B=nb)
+                with lock:
+                    stage_sum[:] += c.last_stage_ms()
+                done.put((toks, lens))
+
+        th = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
+        for t in th:
+            t.start()
+        for _ in range(n_steps):
+            toks, lens = done.get()
+            if use_dist:
+                # the only exchange of the whole job: one fixed-stride all-gather of the token streams per step
+                gathered = sharding.gather_tokens(dist, toks, lens, nb * world, world, device="cuda")
+        for t in th:
+            t.join()
+        return stage_sum
 
     def sync_all():
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(max(args.warmup, 1) * S if args.warmup > 0 else 0)   # every context warmed (graph captured)
     sync_all()
     t0 = time.perf_counter()
-    stage = np.zeros(3)
-    for _ in range(args.steps):
-        toks, lens = step()
-        stage += ctx.last_stage_ms()
+    stage = run_steps(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -211,13 +244,24 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # for transparency: the same workload with ONE batch in flight (latency of a single batch of nb chunks)
+    single_ms = None
+    if S > 1:
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            ctx.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE, pcm_dtype=B.WM_I16, B=nb)
+        ctx.sync()
+        single_ms = (time.perf_counter() - t1) / 2 * 1e3
+
     # second pass of the SAME steps with per-launch HIP events on the launch stream
     roof = None
     prof = {}
     if rank == 0:
         ctx.profile_reset()
         ctx.profile_enable(True)
-        for _ in range(args.steps):
+        n_prof = min(args.steps, 3)
+        for _ in range(n_prof):
             ctx.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE, pcm_dtype=B.WM_I16, B=nb)
         prof = ctx.profile()
         ctx.profile_enable(False)
@@ -287,7 +331,8 @@ def main():
         total_audio = 30.0 * nb * world * args.steps
         dec_steps = len(prompt) + max_new - 1
         stage_s = stage / 1e3 / max(args.steps, 1)
-        fams = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["n"] / args.steps,
+        n_prof = min(args.steps, 3)
+        fams = {k: {"ms_per_step": v["ms"] / n_prof, "launches_per_step": v["n"] / n_prof,
                     "avg_us": v["ms"] / v["n"] * 1e3} for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         line = {
             "metric": "audio-sec/s (RTF) + decoder tok/s, Whisper-large-v2 30s chunks, 1->8 GPU",
@@ -297,17 +342,23 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "whisper-%s geometry, random-init weights, %d x 30 s int16 chunks per GPU "
-                                   "resident in HBM, greedy %d new tokens (EOT suppressed), prompt %d tokens"
-                                   % (args.model, nb, max_new, len(prompt)),
-                       "chunks_per_gpu": nb, "new_tokens": max_new, "parallelism": "chunk-dp%d" % world},
+            "config": {"workload": "whisper-%s geometry, random-init weights, batches of %d x 30 s int16 chunks resident "
+                                   "in HBM, greedy %d new tokens (EOT suppressed), prompt %d tokens; a step = one batch; "
+                                   "%d independent batches in flight per GPU (one HIP stream + KV cache each, weights shared)"
+                                   % (args.model, nb, max_new, len(prompt), S),
+                       "chunks_per_gpu": nb, "new_tokens": max_new, "inflight_batches_per_gpu": S,
+                       "parallelism": "chunk-dp%d" % world},
             "rtf": dt / total_audio,
-            "decoder_tok_per_s": (nb * world * max_new) / max(stage_s[2], 1e-9),
+            "decoder_tok_per_s": (S * nb * world * max_new) / max(stage_s[2], 1e-9),   # S pipelines decode concurrently
+            "tok_per_s_end_to_end": (nb * world * max_new * args.steps) / dt,
+            "inflight_batches_per_gpu": S,
+            "single_batch_latency_ms": single_ms,
+            "value_one_batch_in_flight": (30.0 * nb / (single_ms * 1e-3)) if single_ms else None,
             "decoder_ms_per_step": stage_s[2] * 1e3 / dec_steps,
             "stage_ms": {"frontend": stage_s[0] * 1e3, "encoder_xkv": stage_s[1] * 1e3, "decode": stage_s[2] * 1e3},
             "roofline": roof,
-            "stage_roofline": stage_rooflines(stage_s, dec_steps),
-            "roofline_note": "mean launch duration from per-launch HIP events (hipEventRecord on the launch stream) in a second pass of the same steps, minus the measured cost of an empty event pair; traffic = 2 x FETCH_SIZE from a separate rocprofv3 --pmc pass (profiles/)",
+            "stage_roofline": stage_rooflines(stage_s / S, dec_steps),   # S pipelines overlap: per-step share of wall time
+            "roofline_note": "mean launch duration from per-launch HIP events (hipEventRecord on the launch stream) in a second pass of the same steps, minus the event-bracketing bias calibrated on a kernel of known device-clock duration; traffic = 2 x FETCH_SIZE from a separate rocprofv3 --pmc pass (profiles/)",
             "cpu_baseline": cpu,
             "kernel_families": fams,
         }
@@ -315,6 +366,8 @@ def main():
     if use_dist:
         dist.barrier()   # rank 0 ran the instrumented pass / CPU baseline: leave together
         dist.destroy_process_group()
+    for c in ctxs[1:]:
+        c.close()
     ctx.close()
 
 

@@ -105,6 +105,11 @@ int wm_init_synthetic(wm_ctx *ctx, uint64_t seed);
 /* Freeze weights: fuse QKV, permute conv taps, precompute tables.  Required before any
  * model call. */
 int wm_finalize(wm_ctx *ctx);
+/* A second context on the same device that SHARES the (finalised, read-only) weights of `parent`
+ * and owns its own HIP stream, activations, KV caches and decode graph.  Independent batches
+ * submitted to different contexts from different host threads overlap on the GPU.  Destroy clones
+ * before their parent. */
+int wm_clone(wm_ctx *parent, wm_ctx **out);
 void wm_destroy(wm_ctx *ctx);
 
 const char *wm_last_error(void);
@@ -157,8 +162,8 @@ int wm_sync(wm_ctx *ctx);
  * totals are read back with wm_profile_get (which synchronises). */
 int wm_profile_enable(wm_ctx *ctx, int on);
 int wm_profile_reset(wm_ctx *ctx);
-/* Mean cost (microseconds) of an EMPTY event-bracketed scope on the launch stream: subtract it from
- * a family's mean launch duration. */
+/* Bias (microseconds) of an event-bracketed launch on this stream, calibrated with a kernel that spins
+ * for a known time of the device clock: subtract it from a family's mean launch duration. */
 int wm_profile_overhead_us(wm_ctx *ctx, float *us);
 /* Writes a JSON object {"family": {"ms": total_ms, "n": launches}, ...} into buf. */
 int wm_profile_json(wm_ctx *ctx, char *buf, size_t buf_bytes);

@@ -86,6 +86,7 @@ def load_library(path=None):
         "wm_logmel": [vp, vp, ip, ip, ip, vp, ip, ip],
         "wm_create_frontend": [ip, pp],
         "wm_create": [ctypes.POINTER(wm_dims), ip, pp],
+        "wm_clone": [vp, pp],
         "wm_set_tensor": [vp, ctypes.c_char_p, vp, sz],
         "wm_get_tensor": [vp, ctypes.c_char_p, vp, sz],
         "wm_load_weights": [vp, ctypes.c_char_p],
@@ -158,6 +159,17 @@ class Context:
             d = wm_dims(**dims) if isinstance(dims, dict) else dims
             _check(self.lib, self.lib.wm_create(ctypes.byref(d), int(device), ctypes.byref(self.handle)))
             self.dims = d.as_dict()
+
+    def clone(self):
+        """Second context sharing this one's finalised weights (own stream / caches): for overlapping
+        independent batches on one GPU from several host threads."""
+        c = Context.__new__(Context)
+        c.lib = self.lib
+        c.handle = ctypes.c_void_p()
+        c.dims = dict(self.dims)
+        c._parent = self   # keep the weight owner alive
+        _check(self.lib, self.lib.wm_clone(self.handle, ctypes.byref(c.handle)))
+        return c
 
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle:

@@ -126,6 +126,18 @@ extern "C" int wm_create(const wm_dims *dims, int device, wm_ctx **out) {
     return st;
 }
 
+extern "C" int wm_clone(wm_ctx *parent, wm_ctx **out) {
+    WM_REQUIRE(parent && out, WM_ERR_INVALID, "null pointer");
+    WM_REQUIRE(parent->model, WM_ERR_STATE, "clone: the parent context has no model");
+    WM_TRY(ctx_new(parent->device, out));
+    int st = wm_model_clone(*out, parent);
+    if (st != WM_OK) {
+        wm_destroy(*out);
+        *out = nullptr;
+    }
+    return st;
+}
+
 extern "C" void wm_destroy(wm_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -202,17 +214,22 @@ extern "C" int wm_profile_json(wm_ctx *ctx, char *buf, size_t n) {
     memcpy(buf, s.c_str(), s.size() + 1);
     return WM_OK;
 }
-// Cost of the measurement itself: mean elapsed time between the two hipEventRecord calls of an
-// EMPTY profiler scope on the launch stream (subtract it from a family's mean launch duration).
+// Cost of the measurement itself.  A kernel that spins for exactly T microseconds of the device
+// clock is bracketed by the same two hipEventRecord calls the profiler uses, queued behind a long
+// kernel so that the host runs ahead of the GPU (as it does in the real pipeline); the bias is the
+// mean (elapsed - T): launch latency of a dependent kernel plus the completion of the closing event.
+int wm_launch_spin(hipStream_t s, int *p, int grid, int cycles);
 extern "C" int wm_profile_overhead_us(wm_ctx *ctx, float *us) {
     WM_TRY(wm_ctx_make_current(ctx));
     WM_REQUIRE(us, WM_ERR_INVALID, "null pointer");
     WM_HIP(hipStreamSynchronize(ctx->stream));
-    const int n = 256;
+    const int n = 64, spin_us = 15;
     std::vector<hipEvent_t> ev(2 * n);
     for (auto &e : ev) WM_HIP(hipEventCreate(&e));
+    WM_TRY(wm_launch_spin(ctx->stream, nullptr, 160, 200000));  // 2 ms head start for the host
     for (int i = 0; i < n; ++i) {
         WM_HIP(hipEventRecord(ev[2 * i], ctx->stream));
+        WM_TRY(wm_launch_spin(ctx->stream, nullptr, 160, spin_us * 100));  // wall_clock64: 100 MHz
         WM_HIP(hipEventRecord(ev[2 * i + 1], ctx->stream));
     }
     WM_HIP(hipStreamSynchronize(ctx->stream));
@@ -223,7 +240,7 @@ extern "C" int wm_profile_overhead_us(wm_ctx *ctx, float *us) {
         tot += ms;
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
-    *us = (float)(tot * 1e3 / n);
+    *us = (float)(tot * 1e3 / n) - (float)spin_us;
     return WM_OK;
 }
 extern "C" int wm_last_stage_ms(wm_ctx *ctx, float out3[3]) {

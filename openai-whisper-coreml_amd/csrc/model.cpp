@@ -41,6 +41,24 @@ static void reg(WmModel *m, const std::string &name, void *ptr, bool is_bf16, si
     m->tensors.push_back(t);
 }
 
+static int alloc_decode_buffers(WmModel *m, hipStream_t s) {
+    const wm_dims &D = m->dims;
+    const int d = D.n_text_state;
+    // decode-step buffers (batch <= WM_DEC_MAXB)
+    WM_TRY(dalloc_t(m, &m->dx, (size_t)WM_DEC_MAXB * d, s));
+    WM_TRY(dalloc_t(m, &m->dq, (size_t)WM_DEC_MAXB * d, s));
+    WM_TRY(dalloc_t(m, &m->dpart, (size_t)WM_DEC_MAXB * D.n_text_head * WM_MAXSPLIT * 66, s));
+    WM_TRY(dalloc_t(m, &m->datt, (size_t)WM_DEC_MAXB * d, s));
+    WM_TRY(dalloc_t(m, &m->dstats, (size_t)(d / 16) * 16 * 2, s));
+    WM_TRY(dalloc_t(m, &m->dhid, (size_t)WM_DEC_MAXB * 4 * d, s));
+    WM_TRY(dalloc_t(m, &m->dlogits, (size_t)WM_DEC_MAXB * m->vpad, s));
+    WM_TRY(dalloc_t(m, &m->dargmax, (size_t)WM_DEC_MAXB * (m->vpad / 16), s));
+    WM_TRY(dalloc_t(m, &m->dresult, WM_DEC_MAXB, s));
+    WM_TRY(dalloc_t(m, &m->dseq, (size_t)WM_DEC_MAXB * (D.n_text_ctx + 1), s));
+    WM_TRY(dalloc_t(m, &m->dpos, 4, s));
+    return WM_OK;
+}
+
 // kinds mirror weights.py: 0 matrix, 1 bias, 2 LN weight, 3 LN bias, 4 sinusoid
 int wm_model_create(wm_ctx *ctx, const wm_dims *dims) {
     const wm_dims &D = *dims;
@@ -144,19 +162,27 @@ int wm_model_create(wm_ctx *ctx, const wm_dims *dims) {
     reg(m, "decoder.ln.weight", m->ln_g, false, d, 2);
     reg(m, "decoder.ln.bias", m->ln_b, false, d, 3);
 
-    // decode-step buffers (batch <= WM_DEC_MAXB)
-    WM_TRY(dalloc_t(m, &m->dx, (size_t)WM_DEC_MAXB * d, s));
-    WM_TRY(dalloc_t(m, &m->dq, (size_t)WM_DEC_MAXB * d, s));
-    WM_TRY(dalloc_t(m, &m->dpart, (size_t)WM_DEC_MAXB * D.n_text_head * WM_MAXSPLIT * 66, s));
-    WM_TRY(dalloc_t(m, &m->datt, (size_t)WM_DEC_MAXB * d, s));
-    WM_TRY(dalloc_t(m, &m->dstats, (size_t)(d / 16) * 16 * 2, s));
-    WM_TRY(dalloc_t(m, &m->dhid, (size_t)WM_DEC_MAXB * 4 * d, s));
-    WM_TRY(dalloc_t(m, &m->dlogits, (size_t)WM_DEC_MAXB * m->vpad, s));
-    WM_TRY(dalloc_t(m, &m->dargmax, (size_t)WM_DEC_MAXB * (m->vpad / 16), s));
-    WM_TRY(dalloc_t(m, &m->dresult, WM_DEC_MAXB, s));
-    WM_TRY(dalloc_t(m, &m->dseq, (size_t)WM_DEC_MAXB * (D.n_text_ctx + 1), s));
-    WM_TRY(dalloc_t(m, &m->dpos, 4, s));
+    WM_TRY(alloc_decode_buffers(m, s));
     WM_HIP(hipStreamSynchronize(s));
+    return WM_OK;
+}
+
+// A second context on the same device that SHARES the parent's (read-only) weights and owns its
+// own stream, activations, KV caches and decode graph: lets independent batches overlap on one GPU
+// (the decode chain is latency-bound, so concurrent batches fill the idle HBM bandwidth).
+int wm_model_clone(wm_ctx *child, const wm_ctx *parent) {
+    const WmModel *pm = parent->model;
+    WM_REQUIRE(pm && pm->finalized, WM_ERR_STATE, "clone: the parent's weights must be finalised");
+    WmModel *m = new WmModel();
+    child->model = m;
+    m->dims = pm->dims; m->finalized = true; m->k1pad = pm->k1pad; m->vpad = pm->vpad;
+    m->conv1_w = pm->conv1_w; m->conv2_w = pm->conv2_w; m->conv1_b = pm->conv1_b; m->conv2_b = pm->conv2_b;
+    m->enc_pos = pm->enc_pos; m->enc = pm->enc; m->ln_post_g = pm->ln_post_g; m->ln_post_b = pm->ln_post_b;
+    m->tok_emb = pm->tok_emb; m->dec_pos = pm->dec_pos; m->dec = pm->dec; m->ln_g = pm->ln_g; m->ln_b = pm->ln_b;
+    m->tensors = pm->tensors; m->index = pm->index;   // registry for wm_get_tensor (pointers alias the parent)
+    m->shares_weights = true;
+    WM_TRY(alloc_decode_buffers(m, child->stream));
+    WM_HIP(hipStreamSynchronize(child->stream));
     return WM_OK;
 }
 
@@ -176,6 +202,7 @@ void wm_model_destroy(wm_ctx *ctx) {
 int wm_model_set_tensor(wm_ctx *ctx, const char *name, const float *data, size_t n) {
     WmModel *m = ctx->model;
     WM_REQUIRE(m, WM_ERR_STATE, "context has no model");
+    WM_REQUIRE(!m->shares_weights, WM_ERR_STATE, "a cloned context shares its parent's weights: set them on the parent");
     WM_REQUIRE(name && data, WM_ERR_INVALID, "null name / data");
     auto it = m->index.find(name);
     WM_REQUIRE(it != m->index.end(), WM_ERR_INVALID, "unknown tensor '%s'", name);
@@ -245,6 +272,7 @@ int wm_model_get_tensor(wm_ctx *ctx, const char *name, float *data, size_t n) {
 int wm_model_init_synthetic(wm_ctx *ctx, uint64_t seed) {
     WmModel *m = ctx->model;
     WM_REQUIRE(m, WM_ERR_STATE, "context has no model");
+    WM_REQUIRE(!m->shares_weights, WM_ERR_STATE, "a cloned context shares its parent's weights");
     const int d = m->dims.n_audio_state;
     for (size_t i = 0; i < m->tensors.size(); ++i) {
         WmTensor &t = m->tensors[i];

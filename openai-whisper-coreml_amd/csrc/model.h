@@ -63,6 +63,7 @@ struct WmTensor {
 struct WmModel {
     wm_dims dims;
     bool finalized = false;
+    bool shares_weights = false;  // clone: weight pointers alias the parent context's (never freed here)
     int k1pad = 0;  // conv1 GEMM K (3*n_mels rounded up to 64)
     int vpad = 0;   // n_vocab rounded up to 16 (token embedding rows)
     // weights
@@ -116,6 +117,7 @@ struct WmModel {
 // model.cpp
 int wm_model_create(wm_ctx *ctx, const wm_dims *dims);
 void wm_model_destroy(wm_ctx *ctx);
+int wm_model_clone(wm_ctx *child, const wm_ctx *parent);
 int wm_model_reserve(wm_ctx *ctx, int B);
 int wm_model_set_tensor(wm_ctx *ctx, const char *name, const float *data, size_t n);
 int wm_model_get_tensor(wm_ctx *ctx, const char *name, float *data, size_t n);

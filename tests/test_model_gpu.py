@@ -326,3 +326,28 @@ def test_wav_to_tokens_pipeline(pkg, tiny, tmp_path):
     toks, lens = A.transcribe_chunks(ctx, chunks, [10, 21], 5)
     direct, _ = ctx.transcribe_greedy(chunks, [10, 21], 5)
     assert np.array_equal(toks, direct) and lens.tolist() == [5, 5]
+
+
+def test_cloned_contexts_overlap_and_agree(pkg, tiny):
+    """wm_clone: weight-sharing contexts driven from concurrent host threads give the parent's exact tokens."""
+    import threading
+    dims, _, _, ctx = tiny
+    pcm, _ = mels(ctx, 2, start=9)
+    want, _ = ctx.transcribe_greedy(pcm, [10, 21], 10)
+    clones = [ctx.clone() for _ in range(2)]
+    got = [None] * 3
+
+    def run(i, c):
+        for _ in range(3):
+            got[i], _ = c.transcribe_greedy(pcm, [10, 21], 10)
+
+    th = [threading.Thread(target=run, args=(i, c)) for i, c in enumerate([ctx] + clones)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for g in got:
+        assert np.array_equal(g, want)
+    with pytest.raises(pkg.binding.WhisperError, match="shares"):
+        clones[0].set_tensor("decoder.ln.bias", np.zeros(128, np.float32))
+    assert np.array_equal(clones[1].get_tensor("decoder.ln.weight", (128,)), ctx.get_tensor("decoder.ln.weight", (128,)))
+    for c in clones:
+        c.close()
