@@ -140,6 +140,8 @@ extern "C" int wm_clone(wm_ctx *parent, wm_ctx **out) {
 
 extern "C" void wm_destroy(wm_ctx *ctx) {
     if (!ctx) return;
+    for (wm_ctx *lane : ctx->lanes) wm_destroy(lane);  // clones go before the weights they alias
+    ctx->lanes.clear();
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     wm_model_destroy(ctx);

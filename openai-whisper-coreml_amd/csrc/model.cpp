@@ -432,6 +432,10 @@ int wm_model_decode_begin(wm_ctx *ctx, int B) {
 
 int wm_model_set_pos(wm_ctx *ctx, int pos) {
     WmModel *m = ctx->model;
+    if (pos == 0) {
+        WM_HIP(hipMemsetAsync(m->dpos, 0, sizeof(int), ctx->stream));  // no host operand: stays asynchronous
+        return WM_OK;
+    }
     WM_HIP(hipMemcpyAsync(m->dpos, &pos, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));  // `pos` is a stack variable
     return WM_OK;

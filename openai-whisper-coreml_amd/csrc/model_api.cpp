@@ -151,6 +151,7 @@ extern "C" int wm_decode_logits(wm_ctx *ctx, const int32_t *tokens, int B, int T
     WM_TRY(wm_model_decode_begin(ctx, B));
     WM_TRY(load_xa(ctx, xa, B, mem));
     WM_HIP(hipMemcpyAsync(m->dseq, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));  // fences `tb`
     WM_TRY(wm_model_set_pos(ctx, 0));
     WM_TRY(wm_model_embed_first(ctx, B));
     float *d_out = logits;
@@ -201,7 +202,8 @@ extern "C" int wm_detect_language(wm_ctx *ctx, const float *xa, int B, int32_t s
     WM_TRY(load_xa(ctx, xa, B, mem));
     std::vector<int32_t> sots(B, sot);  // Whisper.swift:34-35
     WM_HIP(hipMemcpyAsync(m->dseq, sots.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
-    WM_TRY(wm_model_set_pos(ctx, 0));                                       // also fences `sots`
+    WM_HIP(hipStreamSynchronize(ctx->stream));                              // fences `sots`
+    WM_TRY(wm_model_set_pos(ctx, 0));
     WM_TRY(wm_model_embed_first(ctx, B));
     WM_TRY(wm_model_decode_step(ctx, B, false, lang_first, lang_last));     // :36-37
     WM_TRY(wm_argmax_embed(ctx, m->dargmax, m->vpad / 16, B, nullptr, nullptr, 0, m->dresult, lang_first, nullptr,
@@ -220,6 +222,99 @@ extern "C" int wm_detect_language(wm_ctx *ctx, const float *xa, int B, int32_t s
 // ------------------------------------------------------------------ greedy transcription
 static size_t pcm_elem(wm_dtype t) { return t == WM_I16 ? 2 : t == WM_F32 ? 4 : 8; }
 
+// ---------------------------------------------------------------- greedy transcription
+// One batch's decode is a chain of ~260 dependent launches per position and is bound by launch latency, not by
+// HBM, so a call with more chunks than one decode group is spread over LANES: weight-sharing
+// clones of the context (wm_clone), each with its own stream, activations, KV caches and decode graph.  The
+// single host thread enqueues the lanes round-robin; the GPU overlaps them.
+namespace {
+constexpr int kGroupChunks = 8;   // preferred chunks per decode group (BASELINE.json configs[3])
+
+int lane_limit() {
+    static const int n = [] {
+        const char *e = getenv("WM_LANES");
+        const int v = e ? atoi(e) : 3;
+        return v < 1 ? 1 : (v > 8 ? 8 : v);
+    }();
+    return n;
+}
+
+struct LaneJob {
+    wm_ctx *c = nullptr;
+    int b0 = 0, Bg = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<int32_t> pr, gen;
+    ~LaneJob() {
+        if (c) (void)hipStreamSynchronize(c->stream);  // error paths: nothing may outlive pr / gen
+        for (auto &e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+};
+
+// front end -> encoder -> cross K/V -> prompt upload -> first embedding, all enqueued on the lane's stream
+int lane_prefill(LaneJob &j, const void *pcm, wm_dtype pcm_dtype, const int32_t *prompt, int n_prompt, wm_mem mem) {
+    wm_ctx *c = j.c;
+    WmModel *m = c->model;
+    const wm_dims &D = m->dims;
+    const int Bg = j.Bg;
+    const size_t bytes = (size_t)Bg * WM_N_SAMPLES * pcm_elem(pcm_dtype);
+    const void *d_pcm = (const char *)pcm + (size_t)j.b0 * WM_N_SAMPLES * pcm_elem(pcm_dtype);
+    if (mem == WM_MEM_HOST) {
+        if (m->pcm_stage_bytes < bytes) {
+            WM_HIP(hipStreamSynchronize(c->stream));
+            if (m->pcm_stage) WM_HIP(hipFree(m->pcm_stage));
+            m->pcm_stage = nullptr;
+            m->pcm_stage_bytes = 0;
+            WM_HIP(hipMalloc(&m->pcm_stage, bytes));
+            m->pcm_stage_bytes = bytes;
+        }
+        WM_HIP(hipMemcpyAsync(m->pcm_stage, d_pcm, bytes, hipMemcpyHostToDevice, c->stream));
+        d_pcm = m->pcm_stage;
+    }
+    // decode state first (prompt tokens [n_prompt][Bg], position 0): a pageable H2D copy may wait for the
+    // stream to drain, so it is issued while the lane is still idle
+    WM_TRY(wm_model_decode_begin(c, Bg));
+    j.pr.resize((size_t)n_prompt * Bg);
+    for (int t = 0; t < n_prompt; ++t)
+        for (int b = 0; b < Bg; ++b) j.pr[(size_t)t * Bg + b] = prompt[t];
+    WM_HIP(hipMemcpyAsync(m->dseq, j.pr.data(), j.pr.size() * 4, hipMemcpyHostToDevice, c->stream));
+    WM_TRY(wm_model_set_pos(c, 0));
+    WM_TRY(wm_model_reserve(c, Bg));
+    WM_HIP(hipEventRecord(j.ev[0], c->stream));
+    // 1. log-mel front end (f32 fast path), output stays in HBM
+    WM_TRY(wm_frontend_run(&c->fe, &c->prof, c->stream, d_pcm, pcm_dtype, Bg, D.n_mels, m->mel_f32, WM_F32));
+    WM_HIP(hipEventRecord(j.ev[1], c->stream));
+    // 2. encoder + cross-attention K/V
+    WM_TRY(wm_model_encode_dev(c, m->mel_f32, Bg, nullptr));
+    WM_TRY(wm_model_cross_kv(c, Bg));
+    WM_HIP(hipEventRecord(j.ev[2], c->stream));
+    // 3. embedding of the first prompt token
+    WM_TRY(wm_model_embed_first(c, Bg));
+    return WM_OK;
+}
+
+// One decoder position = 8 launches per layer + logits + arg-max/embed (which writes the next token, embeds the
+// next position and advances *dpos).  Nothing in it depends on host state, so it is captured ONCE into a
+// hipGraph per lane and replayed for every position.
+int lane_graph(LaneJob &j, int n_prompt) {
+    wm_ctx *c = j.c;
+    WmModel *m = c->model;
+    if (m->graph_exec && m->graph_B == j.Bg && m->graph_n_prompt == n_prompt && m->graph_cap_b == m->cap_b)
+        return WM_OK;
+    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+    WM_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    int crc = wm_model_decode_step(c, j.Bg, false, 0, m->dims.n_vocab - 1);
+    if (crc == WM_OK) crc = wm_model_close_step(c, j.Bg, n_prompt, true, nullptr, 0);
+    hipError_t ce = hipStreamEndCapture(c->stream, &m->graph);
+    if (crc != WM_OK) return crc;
+    WM_HIP(ce);
+    WM_HIP(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+    m->graph_B = j.Bg; m->graph_n_prompt = n_prompt; m->graph_cap_b = m->cap_b;
+    return WM_OK;
+}
+}  // namespace
+
 extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int B,
                                     const int32_t *prompt, int n_prompt, int max_new, int32_t eot,
                                     int32_t *tokens_out, int32_t *lens_out, wm_mem mem) {
@@ -233,94 +328,79 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
                "prompt (%d) + new tokens (%d) must fit the %d-token context", n_prompt, max_new, D.n_text_ctx);
     for (int i = 0; i < n_prompt; ++i)
         WM_REQUIRE(prompt[i] >= 0 && prompt[i] < D.n_vocab, WM_ERR_INVALID, "prompt token %d out of range", prompt[i]);
-    const size_t chunk_b = (size_t)WM_N_SAMPLES * pcm_elem(pcm_dtype);
-    hipEvent_t ev[4];
-    for (auto &e : ev) WM_HIP(hipEventCreate(&e));
-    ctx->stage_ms[0] = ctx->stage_ms[1] = ctx->stage_ms[2] = 0.f;
-    int rc = WM_OK;
-    // the decoder kernels take <= 16 sequences: larger batches run as consecutive groups
-    for (int b0 = 0; b0 < B && rc == WM_OK; b0 += WM_DEC_MAXB) {
-        const int Bg = (B - b0) < WM_DEC_MAXB ? (B - b0) : WM_DEC_MAXB;
-        const void *d_pcm = (const char *)pcm + (size_t)b0 * chunk_b;
-        if (mem == WM_MEM_HOST) {
-            if (m->pcm_stage_bytes < (size_t)Bg * chunk_b) {
-                WM_HIP(hipStreamSynchronize(ctx->stream));
-                if (m->pcm_stage) WM_HIP(hipFree(m->pcm_stage));
-                m->pcm_stage = nullptr;
-                WM_HIP(hipMalloc(&m->pcm_stage, (size_t)Bg * chunk_b));
-                m->pcm_stage_bytes = (size_t)Bg * chunk_b;
-            }
-            WM_HIP(hipMemcpyAsync(m->pcm_stage, d_pcm, (size_t)Bg * chunk_b, hipMemcpyHostToDevice, ctx->stream));
-            d_pcm = m->pcm_stage;
-        }
-        if ((rc = wm_model_reserve(ctx, Bg)) != WM_OK) break;
-        WM_HIP(hipEventRecord(ev[0], ctx->stream));
-        // 1. log-mel front end (f32 fast path), output stays in HBM
-        if ((rc = wm_frontend_run(&ctx->fe, &ctx->prof, ctx->stream, d_pcm, pcm_dtype, Bg, D.n_mels, m->mel_f32,
-                                  WM_F32)) != WM_OK) break;
-        WM_HIP(hipEventRecord(ev[1], ctx->stream));
-        // 2. encoder + cross-attention K/V
-        if ((rc = wm_model_encode_dev(ctx, m->mel_f32, Bg, nullptr)) != WM_OK) break;
-        if ((rc = wm_model_cross_kv(ctx, Bg)) != WM_OK) break;
-        WM_HIP(hipEventRecord(ev[2], ctx->stream));
-        // 3. greedy decode: prompt positions, then max_new generated tokens
-        if ((rc = wm_model_decode_begin(ctx, Bg)) != WM_OK) break;
-        std::vector<int32_t> pr((size_t)n_prompt * Bg);
-        for (int t = 0; t < n_prompt; ++t)
-            for (int b = 0; b < Bg; ++b) pr[(size_t)t * Bg + b] = prompt[t];
-        WM_HIP(hipMemcpyAsync(m->dseq, pr.data(), pr.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        if ((rc = wm_model_set_pos(ctx, 0)) != WM_OK) break;
-        if ((rc = wm_model_embed_first(ctx, Bg)) != WM_OK) break;
-        const int n_steps = n_prompt + max_new - 1;
-        // One decoder position = 8 launches per layer + logits + arg-max/embed (which writes the
-        // next token, embeds the next position and advances *dpos).  Nothing in it depends on host state, so it is
-        // captured ONCE into a hipGraph and replayed for every position.
-        static const bool no_graph = getenv("WM_NO_GRAPH") != nullptr;
-        const bool use_graph = !no_graph && !ctx->prof.on;
-        if (use_graph && (m->graph_exec == nullptr || m->graph_B != Bg || m->graph_n_prompt != n_prompt ||
-                          m->graph_cap_b != m->cap_b)) {
-            if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-            if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
-            WM_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-            int crc = wm_model_decode_step(ctx, Bg, false, 0, D.n_vocab - 1);
-            if (crc == WM_OK) crc = wm_model_close_step(ctx, Bg, n_prompt, true, nullptr, 0);
-            hipError_t ce = hipStreamEndCapture(ctx->stream, &m->graph);
-            if (crc != WM_OK) { rc = crc; break; }
-            WM_HIP(ce);
-            WM_HIP(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
-            m->graph_B = Bg; m->graph_n_prompt = n_prompt; m->graph_cap_b = m->cap_b;
-        }
-        for (int t = 0; t < n_steps && rc == WM_OK; ++t) {
-            if (use_graph) {
-                WM_HIP(hipGraphLaunch(m->graph_exec, ctx->stream));
-            } else {
-                rc = wm_model_decode_step(ctx, Bg, false, 0, D.n_vocab - 1);
-                if (rc == WM_OK) rc = wm_model_close_step(ctx, Bg, n_prompt, true, nullptr, 0);
-            }
-        }
-        if (rc != WM_OK) break;
-        WM_HIP(hipEventRecord(ev[3], ctx->stream));
-        std::vector<int32_t> gen((size_t)max_new * Bg);  // dseq[n_prompt + i][b]
-        WM_HIP(hipMemcpyAsync(gen.data(), m->dseq + (size_t)n_prompt * Bg, gen.size() * 4, hipMemcpyDeviceToHost,
-                              ctx->stream));
-        WM_HIP(hipStreamSynchronize(ctx->stream));
-        std::vector<int32_t> hist((size_t)Bg * max_new);
-        for (int b = 0; b < Bg; ++b)
-            for (int i = 0; i < max_new; ++i) hist[(size_t)b * max_new + i] = gen[(size_t)i * Bg + b];
-        for (int b = 0; b < Bg; ++b) {
-            int len = max_new;
-            for (int i = 0; i < max_new; ++i)
-                if (eot >= 0 && hist[(size_t)b * max_new + i] == eot) { len = i + 1; break; }
-            for (int i = 0; i < max_new; ++i)
-                tokens_out[(size_t)(b0 + b) * max_new + i] = i < len ? hist[(size_t)b * max_new + i] : eot;
-            lens_out[b0 + b] = len;
-        }
-        float ms;
-        for (int i = 0; i < 3; ++i)
-            if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) ctx->stage_ms[i] += ms;
+    static const bool no_graph = getenv("WM_NO_GRAPH") != nullptr;
+    const bool use_graph = !no_graph && !ctx->prof.on;
+    // Split the B chunks into G balanced decode groups (<= WM_DEC_MAXB each, kGroupChunks preferred) and run
+    // them L lanes at a time.  Per-kernel profiling keeps everything on the caller's context (one lane).
+    const int L = ctx->prof.on ? 1 : lane_limit();
+    int G;
+    if (B <= kGroupChunks * L) {
+        G = (B + kGroupChunks - 1) / kGroupChunks;
+    } else {
+        G = (B + WM_DEC_MAXB - 1) / WM_DEC_MAXB;
+        if (G < L) G = L;
+        G = (G + L - 1) / L * L;
     }
-    for (auto &e : ev) (void)hipEventDestroy(e);
-    return rc;
+    const int n_lanes = G < L ? G : L;
+    while ((int)ctx->lanes.size() < n_lanes - 1) {
+        wm_ctx *c = nullptr;
+        WM_TRY(wm_clone(ctx, &c));
+        ctx->lanes.push_back(c);
+    }
+    std::vector<LaneJob> jobs(n_lanes);
+    for (int l = 0; l < n_lanes; ++l) {
+        jobs[l].c = l == 0 ? ctx : ctx->lanes[l - 1];
+        for (auto &e : jobs[l].ev) WM_HIP(hipEventCreate(&e));
+    }
+    ctx->stage_ms[0] = ctx->stage_ms[1] = ctx->stage_ms[2] = 0.f;
+    const int n_steps = n_prompt + max_new - 1;
+    const int base = B / G, rem = B % G;
+    for (int g0 = 0; g0 < G; g0 += n_lanes) {
+        const int nl = (G - g0) < n_lanes ? (G - g0) : n_lanes;
+        for (int l = 0; l < nl; ++l) {
+            LaneJob &j = jobs[l];
+            const int g = g0 + l;
+            j.Bg = base + (g < rem ? 1 : 0);
+            j.b0 = g * base + (g < rem ? g : rem);
+            WM_TRY(lane_prefill(j, pcm, pcm_dtype, prompt, n_prompt, mem));
+            if (use_graph) WM_TRY(lane_graph(j, n_prompt));
+        }
+        for (int t = 0; t < n_steps; ++t)
+            for (int l = 0; l < nl; ++l) {
+                LaneJob &j = jobs[l];
+                if (use_graph) {
+                    WM_HIP(hipGraphLaunch(j.c->model->graph_exec, j.c->stream));
+                } else {
+                    WM_TRY(wm_model_decode_step(j.c, j.Bg, false, 0, D.n_vocab - 1));
+                    WM_TRY(wm_model_close_step(j.c, j.Bg, n_prompt, true, nullptr, 0));
+                }
+            }
+        for (int l = 0; l < nl; ++l) {
+            LaneJob &j = jobs[l];
+            WM_HIP(hipEventRecord(j.ev[3], j.c->stream));
+            j.gen.resize((size_t)max_new * j.Bg);  // dseq[n_prompt + i][b]
+            WM_HIP(hipMemcpyAsync(j.gen.data(), j.c->model->dseq + (size_t)n_prompt * j.Bg, j.gen.size() * 4,
+                                  hipMemcpyDeviceToHost, j.c->stream));
+        }
+        float wave_ms[3] = {0.f, 0.f, 0.f};
+        for (int l = 0; l < nl; ++l) {
+            LaneJob &j = jobs[l];
+            WM_HIP(hipStreamSynchronize(j.c->stream));
+            for (int b = 0; b < j.Bg; ++b) {
+                int len = max_new;
+                for (int i = 0; i < max_new; ++i)
+                    if (eot >= 0 && j.gen[(size_t)i * j.Bg + b] == eot) { len = i + 1; break; }
+                for (int i = 0; i < max_new; ++i)
+                    tokens_out[(size_t)(j.b0 + b) * max_new + i] = i < len ? j.gen[(size_t)i * j.Bg + b] : eot;
+                lens_out[j.b0 + b] = len;
+            }
+            float ms;
+            for (int i = 0; i < 3; ++i)
+                if (hipEventElapsedTime(&ms, j.ev[i], j.ev[i + 1]) == hipSuccess && ms > wave_ms[i]) wave_ms[i] = ms;
+        }
+        for (int i = 0; i < 3; ++i) ctx->stage_ms[i] += wave_ms[i];  // lanes overlap: slowest lane per stage
+    }
+    return WM_OK;
 }
 
 // ------------------------------------------------------------------ per-kernel test hooks

@@ -116,6 +116,7 @@ struct wm_ctx {
     WmFrontend fe;
     WmModel *model = nullptr;
     float stage_ms[3] = {0, 0, 0};
+    std::vector<wm_ctx *> lanes;  // weight-sharing clones owned by this context (wm_transcribe_greedy)
 };
 
 int wm_ctx_make_current(const wm_ctx *ctx);
