@@ -55,6 +55,14 @@ int wmdbg_bench_launch_floor(wm_ctx *ctx, int iters, int grid, float *eager_us, 
  * independent chains: tells whether hipGraph runs parallel branches concurrently on this runtime. */
 int wmdbg_bench_graph_branches(wm_ctx *ctx, int iters, int grid, int us_each, float *one_us, float *two_us);
 
+/* Mean duration (us) of one encoder GEMM launch, C[M][N] = A[M][K] W[N][K]^T, back to back, on encoder-like operands
+ * (A ~ N(0,1), W ~ N(0,0.02^2)); launches rotate over n_w copies of W (n_w large: W streams from HBM as in the model). */
+int wmdbg_bench_gemm(wm_ctx *ctx, int M, int N, int K, int epi, int iters, int n_w, float *us);
+
+/* Force the encoder GEMM tile: 128 (128 x 128, 4 waves), 256 (256 x 256, 8 waves, staggered phases) or 0 = automatic.
+ * Process-wide; used by the parity tests and A/B probes to run every shape through both kernels. */
+int wmdbg_set_gemm_tile(int tile);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,26 +55,120 @@ struct GemmDev {
     int group_m;
 };
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
-    __shared__ __attribute__((aligned(16))) char lds[2][2][TILE_BYTES];  // [buf][A|B]
+// Epilogue of one wave's MI x NJ accumulator fragments.  Fragment (i, j): this lane holds column
+// n = ncol0 + j*16 and rows mrow0 + i*16 + {0..3}.  Everything that depends only on the row (the batched
+// row -> address map, which needs an integer division) or only on the column (bias, head / feature split)
+// is computed once per row / column, not per element: the epilogue is VALU work that nothing overlaps when a
+// CU holds a single workgroup.
+template <int EPI, int MI, int NJ>
+__device__ __forceinline__ void store_tile(const GemmDev &p, const f32x4 (&acc)[MI][NJ], int mrow0, int ncol0) {
+    float bv[NJ];
+    long coff[NJ];   // column part of the destination offset (EPI_XKV; V^T part of EPI_QKV_ENC)
+    bool vpart[NJ];  // EPI_QKV_ENC: this column belongs to the value projection
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int n = ncol0 + j * 16;
+        const int nc = n < p.N ? n : p.N - 1;
+        bv[j] = p.bias ? p.bias[nc] : 0.f;
+        coff[j] = 0;
+        vpart[j] = false;
+        if (EPI == EPI_XKV) {  // n -> (kv, h, e); out[kv][b][h][s][e]
+            const int kv = nc / p.d_model, hn = nc - kv * p.d_model, h = hn >> 6, e = hn & 63;
+            coff[j] = ((long)(kv * p.batch) * p.n_head + h) * p.seq * 64 + e;
+        } else if (EPI == EPI_QKV_ENC) {  // value columns -> V^T [b][h][e][seq_pad]
+            vpart[j] = nc >= 2 * p.d_model;
+            const int hn = nc - 2 * p.d_model, h = hn >> 6, e = hn & 63;
+            coff[j] = ((long)h * 64 + e) * p.seq_pad;
+        }
+    }
+    const unsigned rpb = (unsigned)p.c_rpb, seq = (unsigned)(p.seq > 0 ? p.seq : 1);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int mb = mrow0 + i * 16;  // first of 4 consecutive rows (mb % 4 == 0)
+        if (mb >= p.M) continue;
+        if (EPI == EPI_QKV_ENC) {
+            // 4 consecutive frames of one chunk (seq % 4 == 0 is not required: rows are checked) -> one 8-B store
+            const unsigned b = (unsigned)mb / seq, sq = (unsigned)mb - b * seq;
+            const long roff = (long)b * p.n_head * 64 * p.seq_pad + sq;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (!vpart[j] || ncol0 + j * 16 >= p.N) continue;
+                const f32x4 &c = acc[i][j];
+                if (sq + 3 < seq && mb + 3 < p.M) {
+                    unsigned lo = (unsigned)f2bf(c[0] + bv[j]) | ((unsigned)f2bf(c[1] + bv[j]) << 16);
+                    unsigned hi = (unsigned)f2bf(c[2] + bv[j]) | ((unsigned)f2bf(c[3] + bv[j]) << 16);
+                    *(uint2 *)(p.vt + roff + coff[j]) = make_uint2(lo, hi);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned m = (unsigned)mb + r;
+                        if ((int)m >= p.M) continue;
+                        const unsigned b2 = m / seq, s2 = m - b2 * seq;
+                        p.vt[(long)b2 * p.n_head * 64 * p.seq_pad + s2 + coff[j]] = f2bf(c[r] + bv[j]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned m = (unsigned)mb + r;
+            if ((int)m >= p.M) continue;
+            long roff;
+            if (EPI == EPI_XKV) {
+                const unsigned b = m / seq, sq = m - b * seq;
+                roff = ((long)b * p.n_head * p.seq + sq) * 64;
+            } else {
+                const unsigned q = m / rpb, rem = m - q * rpb;
+                roff = (long)q * p.c_bstride + (long)rem * p.c_rstride;
+            }
+            const float *pos_row = EPI == EPI_CONV2_F32 ? p.pos + (long)(m % rpb) * p.N : nullptr;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = ncol0 + j * 16;
+                if (n >= p.N) continue;
+                const float v = acc[i][j][r] + bv[j];
+                if (EPI == EPI_XKV) {
+                    ((bf16_t *)p.C)[roff + coff[j]] = f2bf(v);
+                } else if (EPI == EPI_QKV_ENC) {
+                    if (!vpart[j]) ((bf16_t *)p.C)[roff + n] = f2bf(v);
+                } else if (EPI == EPI_BIAS_BF16) {
+                    ((bf16_t *)p.C)[roff + n] = f2bf(v);
+                } else if (EPI == EPI_GELU_BF16) {
+                    ((bf16_t *)p.C)[roff + n] = f2bf(gelu_erf(v));
+                } else if (EPI == EPI_RESID_F32) {
+                    ((float *)p.C)[roff + n] += v;
+                } else if (EPI == EPI_CONV2_F32) {
+                    ((float *)p.C)[roff + n] = gelu_erf(v) + pos_row[n];
+                } else {  // EPI_F32
+                    ((float *)p.C)[roff + n] = v;
+                }
+            }
+        }
+    }
+}
 
-    // ---- XCD-aware, bijective workgroup -> tile map -------------------------------------
+// XCD-aware, bijective workgroup -> tile map: the 8 XCDs (private L2s) each get a contiguous range of tiles,
+// walked in GM x tiles_n groups so that the tiles an XCD runs concurrently share A and W panels in its L2.
+__device__ __forceinline__ void tile_of_workgroup(const GemmDev &p, int &tm, int &tn) {
     const int nwg = p.tiles_m * p.tiles_n;
     int wg = blockIdx.x;
-    {
-        const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
-    }
-    // grouped tile order inside each XCD's contiguous range: the ~64 tiles an XCD runs concurrently
-    // form a GM x 8 block (GM A panels + 8 W panels live in its 4 MiB L2) instead of 1 x 64
-    // (1 A panel + 64 W panels).  Worth 3-7 % on the encoder GEMMs (measured; not the main limiter).
+    const int xcd = wg & 7, q = nwg >> 3, r = nwg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
     const int GM = p.group_m;
     const int per_group = GM * p.tiles_n;
     const int grp = wg / per_group, in_grp = wg % per_group;
     const int first_m = grp * GM;
     const int gsz = (p.tiles_m - first_m) < GM ? (p.tiles_m - first_m) : GM;
-    const int tm = first_m + in_grp % gsz, tn = in_grp / gsz;
+    tm = first_m + in_grp % gsz;
+    tn = in_grp / gsz;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
+    __shared__ __attribute__((aligned(16))) char lds[2][2][TILE_BYTES];  // [buf][A|B]
+
+    int tm, tn;
+    tile_of_workgroup(p, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -150,58 +244,200 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
     }
 
     // ---- epilogue: D fragment (i,j): col n = lane & 15, rows m = (lane >> 4) * 4 + r ------
+    store_tile<EPI, 4, 4>(p, acc, m0 + wr * 64 + fq * 4, n0 + wc * 64 + frow);
+}
+
+// =================================================================================================
+// 256 x 256 x 64 tile for the large encoder products: 512 threads = 8 wave64 as 2(M) x 4(N), each wave
+// owns 128 x 64 of C (8 x 4 fragments, 128 accumulator registers); one workgroup per CU (128 KiB LDS).
+//
+// A K-tile (64 KiB in LDS, two buffers) is staged as four 16-KiB UNITS grouped by WHEN they are consumed:
+//     S0 = A rows {0..63, 128..191}  (m-fragments 0-3 of both wave rows)      read in phase 1
+//     S1 = W rows {wc*64 + 0..31}    (n-fragments 0-1 of the four wave columns) read in phase 1
+//     S2 = W rows {wc*64 + 32..63}   (n-fragments 2-3)                          read in phase 2
+//     S3 = A rows {64..127, 192..255} (m-fragments 4-7)                         read in phase 3
+// and computed as four phases of 16 MFMAs (one 64 x 32 quadrant of the wave's C x K = 64):
+//     P1 (A0,B0)   P2 (A0,B1)   P3 (A1,B1)   P4 (A1,B0: registers only)
+// Every phase also issues ONE unit of the stream S0(t),S1(t),S2(t),S3(t),S0(t+1),... six units ahead of
+// the phase that reads it (global_load_lds, 2 x 16 B per lane), and waits with a COUNTED s_waitcnt vmcnt(8):
+// four units stay in flight across the barriers, the unit read by the next phase has landed.  A unit is
+// re-staged no earlier than two phases after its last ds_read.  The two wave rows run one barrier apart
+// (wr = 1 enters through an extra s_barrier), so on every SIMD one wave issues ds_reads / DMA while the
+// other runs its MFMA cluster.  The ds_reads are inline asm: hipcc would otherwise put a vmcnt(0) in front
+// of every LDS read that may alias an outstanding LDS-DMA and serialise the pipeline.
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int UNIT_BYTES = 128 * BK * 2;   // 16 KiB
+constexpr int BUF_BYTES = 4 * UNIT_BYTES;  // 64 KiB per K-tile
+
+#define WM_DSR(dst, addr, off) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+#define WM_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <int EPI>
+__global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_per_eu(2, 2))) void gemm256_bf16_kernel(
+    GemmDev p) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * BUF_BYTES];
+
+    int tm, tn;
+    tile_of_workgroup(p, tm, tn);
+    const int m0 = tm * BM2, n0 = tn * BN2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    // ---- staging sources: a unit is 2 passes of 64 unit-rows x 8 chunks of 16 B -----------------------
+    // thread -> unit-row u = pass*64 + tid/8, physical chunk tid%8, fetching logical chunk (pch ^ (u & 7)).
+    const int srow = tid >> 3, pch = tid & 7;
+    const int lch8 = (pch ^ (srow & 7)) * 8;
+    const bf16_t *a_src[2][2];  // [sub][pass]
+    const bf16_t *w_src[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int mb = m0 + wr * 64 + i * 16 + fq * 4;  // first of 4 consecutive rows
+    for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wc * 64 + j * 16 + frow;
-            if (n >= p.N) continue;
-            const float bv = p.bias ? p.bias[n] : 0.f;
-            if (EPI == EPI_QKV_ENC && n >= 2 * p.d_model) {
-                // value projection -> V^T [b][h][e][seq_pad]: 4 consecutive frames, one 8-B store
-                if (mb < p.M) {
-                    const int b = mb / p.seq, s = mb % p.seq;
-                    const int hn = n - 2 * p.d_model, h = hn >> 6, e = hn & 63;
-                    unsigned lo = (unsigned)f2bf(acc[i][j][0] + bv) | ((unsigned)f2bf(acc[i][j][1] + bv) << 16);
-                    unsigned hi = (unsigned)f2bf(acc[i][j][2] + bv) | ((unsigned)f2bf(acc[i][j][3] + bv) << 16);
-                    bf16_t *dst = p.vt + (((long)(b * p.n_head + h) * 64 + e) * p.seq_pad + s);
-                    *(uint2 *)dst = make_uint2(lo, hi);
-                }
-                continue;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long m = mb + r;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (EPI == EPI_XKV) {
-                    // n -> (kv, h, e); out[kv][b][h][s][e]
-                    const int kv = n / p.d_model, hn = n % p.d_model, h = hn >> 6, e = hn & 63;
-                    const int b = (int)(m / p.seq), s = (int)(m % p.seq);
-                    bf16_t *dst = (bf16_t *)p.C +
-                                  ((((long)kv * p.batch + b) * p.n_head + h) * p.seq + s) * 64 + e;
-                    *dst = f2bf(v);
-                    continue;
-                }
-                const long co = (m / p.c_rpb) * p.c_bstride + (m % p.c_rpb) * p.c_rstride + n;
-                if (EPI == EPI_BIAS_BF16 || EPI == EPI_QKV_ENC) {
-                    ((bf16_t *)p.C)[co] = f2bf(v);
-                } else if (EPI == EPI_GELU_BF16) {
-                    ((bf16_t *)p.C)[co] = f2bf(gelu_erf(v));
-                } else if (EPI == EPI_RESID_F32) {
-                    ((float *)p.C)[co] += v;
-                } else if (EPI == EPI_CONV2_F32) {
-                    ((float *)p.C)[co] = gelu_erf(v) + p.pos[(m % p.c_rpb) * (long)p.N + n];
-                } else {  // EPI_F32
-                    ((float *)p.C)[co] = v;
-                }
-            }
+        for (int i = 0; i < 2; ++i) {
+            long m = m0 + i * 128 + sub * 64 + srow;  // pass i = wave row i
+            if (m > p.M - 1) m = p.M - 1;             // clamp: tail rows are masked in the epilogue
+            a_src[sub][i] = p.A + (m / p.a_rpb) * p.a_bstride + (m % p.a_rpb) * p.a_rstride + lch8;
+            long n = n0 + (2 * i + (srow >> 5)) * 64 + sub * 32 + (srow & 31);  // unit-row -> (wave col, row)
+            if (n > p.N - 1) n = p.N - 1;
+            w_src[sub][i] = p.W + n * (long)p.K + lch8;
         }
+    auto issue = [&](const bf16_t *s0, const bf16_t *s1, int lds_off, long ko) {
+        char *d0 = lds + lds_off + wave * 1024;  // wave-uniform base; the hardware adds lane * 16
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s0 + ko),
+                                         (__attribute__((address_space(3))) void *)d0, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(s1 + ko),
+                                         (__attribute__((address_space(3))) void *)(d0 + 8192), 16, 0, 0);
+    };
+    // stream index -> (K-tile, unit): unit 0 = S0, 1 = S1, 2 = S2, 3 = S3
+#define WM_ISSUE(unit, tile)                                                                                   \
+    do {                                                                                                       \
+        const int t_ = (tile);                                                                                 \
+        const int off_ = (t_ & 1) * BUF_BYTES + (unit) * UNIT_BYTES;                                           \
+        const long ko_ = (long)t_ * BK;                                                                        \
+        if ((unit) == 0) issue(a_src[0][0], a_src[0][1], off_, ko_);                                           \
+        else if ((unit) == 1) issue(w_src[0][0], w_src[0][1], off_, ko_);                                      \
+        else if ((unit) == 2) issue(w_src[1][0], w_src[1][1], off_, ko_);                                      \
+        else issue(a_src[1][0], a_src[1][1], off_, ko_);                                                       \
+    } while (0)
+
+    // ---- fragment read addresses (32-bit LDS offsets): unit-row u = wr*64 + i*16 + frow (A) or
+    // wc*32 + j*16 + frow (W); the swizzle term only depends on frow, the k-step toggles chunk bit 2.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+    const unsigned sw0 = (unsigned)((fq ^ (frow & 7)) << 4);
+    const unsigned a_rd = lds0 + (unsigned)((wr * 64 + frow) * 128) + sw0;
+    const unsigned b_rd = lds0 + (unsigned)((wc * 32 + frow) * 128) + sw0;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 a[4][2], b0[2][2], b1[2][2];  // [fragment][k-step]
+
+#define WM_MFMA_QUAD(mq, bb, jb)                                                                               \
+    do {                                                                                                       \
+        __builtin_amdgcn_s_setprio(1);                                                                         \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                  \
+                    acc[(mq) * 4 + i][(jb) + j] =                                                              \
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][ks], bb[j][ks], acc[(mq) * 4 + i][(jb) + j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                         \
+    } while (0)
+
+    // One phase.  P: 0..3; ISSUE: stage stream unit (P + 2) & 3 of K-tile t + 1 (P < 2) or t + 2; VM: vmcnt.
+#define WM_PHASE(P, ISSUE, VM, t)                                                                              \
+    do {                                                                                                       \
+        const unsigned bo_ = (unsigned)(((t) & 1) * BUF_BYTES);                                                \
+        const unsigned ar0_ = a_rd + bo_, ar1_ = (a_rd ^ 64u) + bo_;                                           \
+        const unsigned br0_ = b_rd + bo_, br1_ = (b_rd ^ 64u) + bo_;                                           \
+        if ((P) == 0) {                                                                                        \
+            WM_DSR(b0[0][0], br0_, UNIT_BYTES); WM_DSR(b0[0][1], br1_, UNIT_BYTES);                            \
+            WM_DSR(b0[1][0], br0_, UNIT_BYTES + 2048); WM_DSR(b0[1][1], br1_, UNIT_BYTES + 2048);              \
+            WM_DSR(a[0][0], ar0_, 0); WM_DSR(a[0][1], ar1_, 0);                                                \
+            WM_DSR(a[1][0], ar0_, 2048); WM_DSR(a[1][1], ar1_, 2048);                                          \
+            WM_DSR(a[2][0], ar0_, 4096); WM_DSR(a[2][1], ar1_, 4096);                                          \
+            WM_DSR(a[3][0], ar0_, 6144); WM_DSR(a[3][1], ar1_, 6144);                                          \
+        } else if ((P) == 1) {                                                                                 \
+            WM_DSR(b1[0][0], br0_, 2 * UNIT_BYTES); WM_DSR(b1[0][1], br1_, 2 * UNIT_BYTES);                    \
+            WM_DSR(b1[1][0], br0_, 2 * UNIT_BYTES + 2048); WM_DSR(b1[1][1], br1_, 2 * UNIT_BYTES + 2048);      \
+        } else if ((P) == 2) {                                                                                 \
+            WM_DSR(a[0][0], ar0_, 3 * UNIT_BYTES); WM_DSR(a[0][1], ar1_, 3 * UNIT_BYTES);                      \
+            WM_DSR(a[1][0], ar0_, 3 * UNIT_BYTES + 2048); WM_DSR(a[1][1], ar1_, 3 * UNIT_BYTES + 2048);        \
+            WM_DSR(a[2][0], ar0_, 3 * UNIT_BYTES + 4096); WM_DSR(a[2][1], ar1_, 3 * UNIT_BYTES + 4096);        \
+            WM_DSR(a[3][0], ar0_, 3 * UNIT_BYTES + 6144); WM_DSR(a[3][1], ar1_, 3 * UNIT_BYTES + 6144);        \
+        }                                                                                                      \
+        if (ISSUE) WM_ISSUE(((P) + 2) & 3, (t) + ((P) < 2 ? 1 : 2));                                           \
+        WM_VMCNT(VM);                                                                                          \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        if ((P) == 0) {                                                                                        \
+            asm volatile("s_waitcnt lgkmcnt(0)"                                                                \
+                         : "+v"(b0[0][0]), "+v"(b0[0][1]), "+v"(b0[1][0]), "+v"(b0[1][1]), "+v"(a[0][0]),      \
+                           "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]), "+v"(a[2][1]),          \
+                           "+v"(a[3][0]), "+v"(a[3][1])::"memory");                                            \
+            WM_MFMA_QUAD(0, b0, 0);                                                                            \
+        } else if ((P) == 1) {                                                                                 \
+            asm volatile("s_waitcnt lgkmcnt(0)"                                                                \
+                         : "+v"(b1[0][0]), "+v"(b1[0][1]), "+v"(b1[1][0]), "+v"(b1[1][1])::"memory");          \
+            WM_MFMA_QUAD(0, b1, 2);                                                                            \
+        } else if ((P) == 2) {                                                                                 \
+            asm volatile("s_waitcnt lgkmcnt(0)"                                                                \
+                         : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[2][0]),          \
+                           "+v"(a[2][1]), "+v"(a[3][0]), "+v"(a[3][1])::"memory");                             \
+            WM_MFMA_QUAD(1, b1, 2);                                                                            \
+        } else {                                                                                               \
+            WM_MFMA_QUAD(1, b0, 0);                                                                            \
+        }                                                                                                      \
+        __builtin_amdgcn_s_barrier();                                                                          \
+    } while (0)
+
+    const int nk = p.K / BK;  // >= 2 (checked by the launcher)
+    // prologue: stream units 0..5 = K-tile 0 complete + S0, S1 of K-tile 1
+    WM_ISSUE(0, 0); WM_ISSUE(1, 0); WM_ISSUE(2, 0); WM_ISSUE(3, 0); WM_ISSUE(0, 1); WM_ISSUE(1, 1);
+    WM_VMCNT(8);  // S0(0), S1(0) have landed
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // wave row 1 runs one barrier behind row 0
+    int t = 0;
+    for (; t < nk - 2; ++t) {
+        WM_PHASE(0, true, 8, t);
+        WM_PHASE(1, true, 8, t);
+        WM_PHASE(2, true, 8, t);
+        WM_PHASE(3, true, 8, t);
     }
+    // last two K-tiles: the stream ends, the counted waits shrink with it
+    WM_PHASE(0, true, 8, t);
+    WM_PHASE(1, true, 8, t);
+    WM_PHASE(2, false, 6, t);
+    WM_PHASE(3, false, 4, t);
+    ++t;
+    WM_PHASE(0, false, 2, t);
+    WM_PHASE(1, false, 0, t);
+    WM_PHASE(2, false, 0, t);
+    WM_PHASE(3, false, 0, t);
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with row 1's last barrier
+
+    store_tile<EPI, 8, 4>(p, acc, m0 + wr * 128 + fq * 4, n0 + wc * 64 + frow);
+#undef WM_PHASE
+#undef WM_MFMA_QUAD
+#undef WM_ISSUE
 }
 
 }  // namespace
+
+static int g_gemm_tile_override = 0;
+extern "C" int wmdbg_set_gemm_tile(int tile) {
+    if (tile != 0 && tile != 128 && tile != 256) return WM_ERR_INVALID;
+    g_gemm_tile_override = tile;
+    return WM_OK;
+}
+
+template <int EPI>
+static void launch_gemm(const GemmDev &p, bool big, int grid, hipStream_t s) {
+    if (big) gemm256_bf16_kernel<EPI><<<grid, 512, 0, s>>>(p);
+    else gemm_bf16_kernel<EPI><<<grid, 256, 0, s>>>(p);
+}
 
 int wm_gemm(wm_ctx *ctx, const GemmArgs &g) {
     WM_REQUIRE(g.K % BK == 0 && g.K >= BK, WM_ERR_INVALID, "gemm: K=%d must be a multiple of %d", g.K, BK);
@@ -212,22 +448,32 @@ int wm_gemm(wm_ctx *ctx, const GemmArgs &g) {
     p.c_rpb = g.c_rpb; p.c_bstride = g.c_bstride; p.c_rstride = g.c_rstride;
     p.M = g.M; p.N = g.N; p.K = g.K; p.pos = g.pos; p.vt = g.vt;
     p.d_model = g.d_model; p.n_head = g.n_head; p.seq = g.seq; p.seq_pad = g.seq_pad; p.batch = g.batch;
-    p.tiles_m = (g.M + BM - 1) / BM;
-    p.tiles_n = (g.N + BN - 1) / BN;
+    // Tile choice: the 256 x 256 staggered-phase kernel once it can put a workgroup on most CUs (one per CU);
+    // the 128 x 128 kernel (two per CU) for everything smaller.  WM_GEMM_TILE=128|256 forces one (tests, A/B).
+    static const int env_tile0 = getenv("WM_GEMM_TILE") ? atoi(getenv("WM_GEMM_TILE")) : 0;
+    const int env_tile = g_gemm_tile_override ? g_gemm_tile_override : env_tile0;
+    const long tiles256 = (long)((g.M + BM2 - 1) / BM2) * ((g.N + BN2 - 1) / BN2);
+    bool big = g.K >= 2 * BK && tiles256 >= 160;
+    if (env_tile == 128) big = false;
+    if (env_tile == 256) big = g.K >= 2 * BK;
+    const int bm = big ? BM2 : BM, bn = big ? BN2 : BN;
+    p.tiles_m = (g.M + bm - 1) / bm;
+    p.tiles_n = (g.N + bn - 1) / bn;
     const int grid = p.tiles_m * p.tiles_n;
     static const int env_gm = getenv("WM_GEMM_GM") ? atoi(getenv("WM_GEMM_GM")) : 0;
     p.group_m = env_gm > 0 ? env_gm : 4;  // measured at large-v2, B = 8: GM 1 / 4 / 8 / 16 -> fc1 341 / 328 / 335 / 335 us
     static const char *names[] = {"gemm_bias_bf16", "gemm_gelu_bf16", "gemm_resid_f32", "gemm_conv2_f32",
                                   "gemm_qkv_enc", "gemm_xkv", "gemm_f32"};
     WmProfScope ps(&ctx->prof, names[g.epi], ctx->stream);
+    hipStream_t st = ctx->stream;
     switch (g.epi) {
-        case EPI_BIAS_BF16: gemm_bf16_kernel<EPI_BIAS_BF16><<<grid, 256, 0, ctx->stream>>>(p); break;
-        case EPI_GELU_BF16: gemm_bf16_kernel<EPI_GELU_BF16><<<grid, 256, 0, ctx->stream>>>(p); break;
-        case EPI_RESID_F32: gemm_bf16_kernel<EPI_RESID_F32><<<grid, 256, 0, ctx->stream>>>(p); break;
-        case EPI_CONV2_F32: gemm_bf16_kernel<EPI_CONV2_F32><<<grid, 256, 0, ctx->stream>>>(p); break;
-        case EPI_QKV_ENC: gemm_bf16_kernel<EPI_QKV_ENC><<<grid, 256, 0, ctx->stream>>>(p); break;
-        case EPI_XKV: gemm_bf16_kernel<EPI_XKV><<<grid, 256, 0, ctx->stream>>>(p); break;
-        case EPI_F32: gemm_bf16_kernel<EPI_F32><<<grid, 256, 0, ctx->stream>>>(p); break;
+        case EPI_BIAS_BF16: launch_gemm<EPI_BIAS_BF16>(p, big, grid, st); break;
+        case EPI_GELU_BF16: launch_gemm<EPI_GELU_BF16>(p, big, grid, st); break;
+        case EPI_RESID_F32: launch_gemm<EPI_RESID_F32>(p, big, grid, st); break;
+        case EPI_CONV2_F32: launch_gemm<EPI_CONV2_F32>(p, big, grid, st); break;
+        case EPI_QKV_ENC: launch_gemm<EPI_QKV_ENC>(p, big, grid, st); break;
+        case EPI_XKV: launch_gemm<EPI_XKV>(p, big, grid, st); break;
+        case EPI_F32: launch_gemm<EPI_F32>(p, big, grid, st); break;
         default: wm_set_error("gemm: bad epilogue %d", g.epi); return WM_ERR_INVALID;
     }
     WM_HIP(hipGetLastError());

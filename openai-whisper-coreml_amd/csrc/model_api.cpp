@@ -733,6 +733,60 @@ extern "C" int wmdbg_bench_launch_floor(wm_ctx *ctx, int iters, int grid, float 
     return WM_OK;
 }
 
+// Mean duration (us) of `iters` back-to-back launches of one encoder GEMM shape.  Operands as in the encoder:
+// A ~ N(0,1), W ~ N(0, 0.02^2), bias ~ 0.01 N(0,1); the launches rotate over `n_w` weight matrices so that W comes
+// from HBM as it does in the 32-layer encoder (n_w = 1: W stays cache-resident).
+extern "C" int wmdbg_bench_gemm(wm_ctx *ctx, int M, int N, int K, int epi, int iters, int n_w, float *us) {
+    WM_TRY(wm_ctx_make_current(ctx));
+    WM_REQUIRE(epi == EPI_F32 || epi == EPI_BIAS_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_F32, WM_ERR_INVALID,
+               "wmdbg_bench_gemm: epilogue %d not exposed", epi);
+    WM_REQUIRE(n_w >= 1 && n_w <= 64, WM_ERR_INVALID, "wmdbg_bench_gemm: n_w out of range");
+    hipStream_t s = ctx->stream;
+    std::vector<bf16_t> a16((size_t)M * K), w16((size_t)N * K);
+    uint32_t x = 12345u;
+    auto gauss = [&]() {  // Irwin-Hall(4), unit variance
+        float acc = 0.f;
+        for (int i = 0; i < 4; ++i) { x = x * 1664525u + 1013904223u; acc += (float)(x >> 8) * (1.0f / 16777216.0f); }
+        return (acc - 2.0f) * 1.7320508f;
+    };
+    auto f2bf = [](float f) {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (bf16_t)(u >> 16);
+    };
+    for (auto &v : a16) v = f2bf(gauss());
+    for (auto &v : w16) v = f2bf(0.02f * gauss());
+    std::vector<float> bias(N);
+    for (auto &v : bias) v = 0.01f * gauss();
+    void *dA, *dB, *dC;
+    std::vector<void *> dW(n_w, nullptr);
+    WM_TRY(up(&dA, a16.data(), a16.size() * 2, s));
+    for (int i = 0; i < n_w; ++i) WM_TRY(up(&dW[i], w16.data(), w16.size() * 2, s));
+    WM_TRY(up(&dB, bias.data(), (size_t)N * 4, s));
+    WM_TRY(up(&dC, nullptr, (size_t)M * N * 4, s));
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = (const bf16_t *)dA; g.a_rpb = (long)M + 1; g.a_rstride = K;
+    g.bias = (const float *)dB; g.C = dC;
+    g.c_rpb = (long)M + 1; g.c_rstride = N; g.M = M; g.N = N; g.K = K; g.epi = epi;
+    hipEvent_t e0, e1;
+    WM_HIP(hipEventCreate(&e0));
+    WM_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) { g.W = (const bf16_t *)dW[i % n_w]; WM_TRY(wm_gemm(ctx, g)); }
+    WM_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) { g.W = (const bf16_t *)dW[i % n_w]; WM_TRY(wm_gemm(ctx, g)); }
+    WM_HIP(hipEventRecord(e1, s));
+    WM_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    WM_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *us = ms * 1e3f / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+    for (void *w : dW) (void)hipFree(w);
+    return WM_OK;
+}
+
 int wm_launch_spin(hipStream_t s, int *p, int grid, int cycles);
 // Do two independent branches of a captured hipGraph run concurrently?  Each branch is a chain of
 // `iters` kernels that spin ~`us_each` microseconds on `grid` workgroups.  Returns wall time of one

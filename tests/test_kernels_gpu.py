@@ -41,9 +41,18 @@ def rel(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
 
 
+@pytest.fixture(params=[128, 256])
+def gemm_tile(ctx, request):
+    """Run a GEMM test through both encoder GEMM kernels (128 x 128 and the 256 x 256 staggered-phase one)."""
+    ctx.lib.wmdbg_set_gemm_tile.argtypes = [ctypes.c_int]
+    assert ctx.lib.wmdbg_set_gemm_tile(request.param) == 0
+    yield request.param
+    ctx.lib.wmdbg_set_gemm_tile(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 256, 192), (1500, 128, 1280),
-                                   (77, 512, 64)])
-def test_gemm_f32_out(ctx, M, N, K):
+                                   (77, 512, 64), (1031, 768, 448), (512, 1280, 5120)])
+def test_gemm_f32_out(ctx, gemm_tile, M, N, K):
     rng = np.random.default_rng(M + N + K)
     A = bf(rng.standard_normal((M, K)))
     Wt = bf(rng.standard_normal((N, K)) * 0.1 + np.linspace(-0.05, 0.05, N)[:, None])  # asymmetric
@@ -55,9 +64,9 @@ def test_gemm_f32_out(ctx, M, N, K):
     assert np.abs(C - ref).max() <= 2e-4 * np.abs(ref).max(), (np.abs(C - ref).max(), np.abs(ref).max())
 
 
-def test_gemm_identity_asymmetric(ctx):
+def test_gemm_identity_asymmetric(ctx, gemm_tile):
     """A = I picks rows of W^T: any row<->col swap in the C write shows up exactly."""
-    M = N = K = 128
+    M = N = K = 128 if gemm_tile == 128 else 512
     A = np.eye(M, K, dtype=np.float32)
     Wt = bf(np.arange(N * K, dtype=np.float32).reshape(N, K) % 251 - 100.0)
     C = np.zeros((M, N), np.float32)
@@ -66,7 +75,7 @@ def test_gemm_identity_asymmetric(ctx):
 
 
 @pytest.mark.parametrize("epi", [0, 1, 2])
-def test_gemm_epilogues(ctx, epi):
+def test_gemm_epilogues(ctx, gemm_tile, epi):
     rng = np.random.default_rng(epi)
     M, N, K = 200, 256, 128
     A = bf(rng.standard_normal((M, K)))
