@@ -5,9 +5,11 @@ geometry, 30 s chunks, batch 8 per GPU (BASELINE.json configs[3]), chunk-paralle
 One "step" = one pass of the hot path over one batch of synthetic 16 kHz audio that is
 already resident in HBM (int16 PCM): log-mel front end -> encoder -> cross-attention K/V
 -> KV-cached greedy decode of 224 tokens (n_text_ctx // 2, EOT suppressed so the work is
-fixed) -> tokens on the host.  Steps are independent batches; --inflight S (default 3) of them
-are kept in flight per GPU on S weight-sharing contexts (the decode chain of one batch is
-latency-bound); the single-batch latency is reported next to the pipelined throughput.  Everything runs through the C ABI of libwhisper_mi355x.so
+fixed) -> tokens on the host.  Steps are independent batches; the engine batches them continuously:
+--fuse F (default 2) consecutive batches are decoded as ONE group of F*8 = 16 chunks (the decoder weights are
+streamed once per group and position), and --inflight S (default 3) groups are kept in flight per GPU on S
+weight-sharing contexts (the decode chain of one group is latency-bound).  The latency of a single batch of 8
+is reported next to the pipelined throughput.  Everything runs through the C ABI of libwhisper_mi355x.so
 (no torch compute; torch is only used for torch.distributed / RCCL at N > 1).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--model large-v2] [--batch 8]
@@ -144,13 +146,16 @@ def cpu_baseline(ctx, dims, pcm16_chunk, prompt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large-v2")
     ap.add_argument("--batch", type=int, default=8, help="30 s chunks per GPU per step")
     ap.add_argument("--new-tokens", type=int, default=224)
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent batches kept in flight per GPU (each on its own HIP stream / context clone)")
+    ap.add_argument("--fuse", type=int, default=2,
+                    help="consecutive steps (batches) decoded together as ONE group of fuse*batch chunks (<= 16): the "
+                         "decoder weights are streamed once per group and position")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -166,6 +171,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
 
+    # this harness supplies the concurrency itself (S host threads x one decode group each): one lane per call
+    os.environ.setdefault("WM_LANES", "1")
     import importlib
     import openai_whisper_coreml_amd as pkg
     B = pkg.binding
@@ -176,7 +183,8 @@ def main():
     ctx.finalize()
 
     nb = args.batch
-    chunks = [structured_pcm16() if i == 0 else synth_pcm16(rank * nb + i) for i in range(nb)]
+    F = max(1, min(args.fuse, 16 // nb if nb <= 16 else 1))
+    chunks = [structured_pcm16() if i == 0 else synth_pcm16(rank * nb * F + i) for i in range(nb * F)]
     pcm = np.stack(chunks)
     d_pcm = ctx.to_device(pcm)
     sot, eot = 50258, 50257
@@ -204,24 +212,31 @@ def main():
 
         def worker(c):
             while True:
-                try:
-                    todo.get_nowait()
-                except queue.Empty:
+                k = 0
+                while k < F:                       # up to F consecutive steps form one decode group
+                    try:
+                        todo.get_nowait()
+                        k += 1
+                    except queue.Empty:
+                        break
+                if k == 0:
                     return
                 toks, lens = c.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE,
-                                                 pcm_dtype=B.WM_I16, B=nb)
+                                                 pcm_dtype=B.WM_I16, B=nb * k)
                 with lock:
                     stage_sum[:] += c.last_stage_ms()
-                done.put((toks, lens))
+                done.put((toks, lens, k))
 
         th = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
         for t in th:
             t.start()
-        for _ in range(n_steps):
-            toks, lens = done.get()
+        finished = 0
+        while finished < n_steps:
+            toks, lens, k = done.get()
+            finished += k
             if use_dist:
-                # the only exchange of the whole job: one fixed-stride all-gather of the token streams per step
-                gathered = sharding.gather_tokens(dist, toks, lens, nb * world, world, device="cuda")
+                # the only exchange of the whole job: one fixed-stride all-gather of the token streams per group
+                gathered = sharding.gather_tokens(dist, toks, lens, nb * k * world, world, device="cuda")
         for t in th:
             t.join()
         return stage_sum
@@ -233,7 +248,7 @@ def main():
         for c in ctxs:
             c.sync()
 
-    run_steps(max(args.warmup, 1) * S if args.warmup > 0 else 0)   # every context warmed (graph captured)
+    run_steps(max(args.warmup, 1) * S * F if args.warmup > 0 else 0)   # every context warmed (graph captured)
     sync_all()
     t0 = time.perf_counter()
     stage = run_steps(args.steps)
@@ -246,7 +261,7 @@ def main():
 
     # for transparency: the same workload with ONE batch in flight (latency of a single batch of nb chunks)
     single_ms = None
-    if S > 1:
+    if S > 1 or F > 1:
         sync_all()
         t1 = time.perf_counter()
         for _ in range(2):
@@ -312,7 +327,8 @@ def main():
                           + La * (8.0 * 1500 * da * da + 4.0 * 1500 * 1500 * da + 16.0 * 1500 * da * da))
         xkv_flops = nb * L * 4.0 * 1500 * d * d
         t_mean = (len(prompt) + max_new) / 2.0
-        dec_bytes = dec_steps * (2.0 * (L * 14 * d * d + V * d) + nb * L * 2 * 1500 * d * 2 + nb * L * 2 * t_mean * d * 2)
+        # per step (= nb chunks): the weights are streamed once per decode group of F steps
+        dec_bytes = dec_steps * (2.0 * (L * 14 * d * d + V * d) / F + nb * L * 2 * 1500 * d * 2 + nb * L * 2 * t_mean * d * 2)
         out = {}
         if stage_s[0] > 0:
             a = fe_bytes / stage_s[0] / 1e9
@@ -344,14 +360,15 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "whisper-%s geometry, random-init weights, batches of %d x 30 s int16 chunks resident "
                                    "in HBM, greedy %d new tokens (EOT suppressed), prompt %d tokens; a step = one batch; "
-                                   "%d independent batches in flight per GPU (one HIP stream + KV cache each, weights shared)"
-                                   % (args.model, nb, max_new, len(prompt), S),
-                       "chunks_per_gpu": nb, "new_tokens": max_new, "inflight_batches_per_gpu": S,
-                       "parallelism": "chunk-dp%d" % world},
+                                   "%d consecutive batches are decoded as one group of %d chunks, %d groups in flight per GPU "
+                                   "(one HIP stream + KV cache each, weights shared)"
+                                   % (args.model, nb, max_new, len(prompt), F, nb * F, S),
+                       "chunks_per_gpu": nb, "new_tokens": max_new, "decode_group_chunks": nb * F,
+                       "inflight_batches_per_gpu": S * F, "parallelism": "chunk-dp%d" % world},
             "rtf": dt / total_audio,
             "decoder_tok_per_s": (S * nb * world * max_new) / max(stage_s[2], 1e-9),   # S pipelines decode concurrently
             "tok_per_s_end_to_end": (nb * world * max_new * args.steps) / dt,
-            "inflight_batches_per_gpu": S,
+            "inflight_batches_per_gpu": S * F,
             "single_batch_latency_ms": single_ms,
             "value_one_batch_in_flight": (30.0 * nb / (single_ms * 1e-3)) if single_ms else None,
             "decoder_ms_per_step": stage_s[2] * 1e3 / dec_steps,

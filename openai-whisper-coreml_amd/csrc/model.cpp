@@ -446,6 +446,8 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
     const wm_dims &D = m->dims;
     const int d = D.n_text_state, H = D.n_text_head, T = D.n_text_ctx, S = 1500;
     const int ns = wm_dec_attn_splits(B, H);
+    static const int env_xns = getenv("WM_XATTN_SPLITS") ? atoi(getenv("WM_XATTN_SPLITS")) : 0;  // A/B probe
+    const int xns = env_xns > 0 ? env_xns : ns;
     int parts = 1;  // who wrote the residual stream last: embedding (1 part) or a DE_RESID GEMV (d/16 parts)
     for (int l = 0; l < D.n_text_layer; ++l) {
         const DecLayerW &L = m->dec[l];
@@ -477,7 +479,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.stats_in = m->dstats; a.stats_parts = parts;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 5. cross-attention over the 1500 cached encoder frames
-        WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, ns, m->dpart, m->datt, true, L.wxo, d, d));
+        WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, xns, m->dpart, m->datt, true, L.wxo, d, d));
         // 6. out-projection + residual
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_BF16; a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wxo; a.bias = L.bxo;
