@@ -147,6 +147,14 @@ int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int B
                          const int32_t *prompt, int n_prompt, int max_new, int32_t eot,
                          int32_t *tokens_out, int32_t *lens_out, wm_mem mem);
 
+/* Logit filters of openai-whisper's greedy decode() (whisper/decoding.py SuppressTokens and SuppressBlank; SURVEY.md 8f
+ * rank 3), applied inside the fused logits / arg-max kernel of wm_transcribe_greedy:
+ *   suppress       : n token ids that are never generated (e.g. the tokenizer's non-speech tokens, sot, translate, ...);
+ *   suppress_first : n_first more ids excluded only for the FIRST generated token (SuppressBlank: " " and <|endoftext|>).
+ * The lists are copied; n = n_first = 0 clears the filter.  wm_decode_logits / wm_detect_language are unaffected (raw
+ * logits).  Contexts made later with wm_clone inherit the filter; existing clones must be set themselves. */
+int wm_set_suppress(wm_ctx *ctx, const int32_t *suppress, int n, const int32_t *suppress_first, int n_first);
+
 /* ------------------------------------------------------------ device memory helpers --- */
 /* For callers that keep inputs resident in HBM (bench.py; a Swift host would use them to
  * avoid the 5.7 MB/chunk PCIe round trip of the reference ABI). */

@@ -303,6 +303,15 @@ class Context:
                                                      lang_last, _ptr(idx), WM_MEM_HOST))
         return idx
 
+    def set_suppress(self, suppress=(), suppress_first=()):
+        """openai-whisper decode() logit filters for transcribe_greedy: `suppress` ids are never generated
+        (SuppressTokens), `suppress_first` ids additionally not as the first generated token (SuppressBlank)."""
+        a = np.ascontiguousarray(list(suppress), dtype=np.int32)
+        b = np.ascontiguousarray(list(suppress_first), dtype=np.int32)
+        self.lib.wm_set_suppress.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        _check(self.lib, self.lib.wm_set_suppress(self.handle, _ptr(a) if a.size else None, int(a.size),
+                                                  _ptr(b) if b.size else None, int(b.size)))
+
     def transcribe_greedy(self, pcm, prompt, max_new, eot=-1, mem=WM_MEM_HOST, pcm_dtype=None, B=None):
         """pcm: host array [B][480000] (int16/float32/float64), or a device pointer
         (c_void_p) with pcm_dtype and B given when mem == WM_MEM_DEVICE."""

@@ -64,6 +64,8 @@ struct DecGemvDev {
     unsigned long long *tilemax;  // [B][n_tiles] (DE_LOGITS)
     int n_tiles;
     int arg_first, arg_last;
+    const unsigned *mask;  // DE_LOGITS: suppressed-token bitmaps [2][mask_words] or null
+    int mask_words, mask_first_pos;
     const char *pf_ptr;   // next GEMV's weights: extra workgroups pull them into this XCD's L2
     long pf_tile_bytes;  // bytes of one 16-row weight tile of that matrix
     int pf_tiles;
@@ -137,9 +139,14 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
     const int nc = nvalid ? n : p.N - 1;
     float bvs = 0.f, xold[4] = {0.f, 0.f, 0.f, 0.f};
     int pos = 0;
+    unsigned mword0 = 0u, mword1 = 0u;
     if (wave == 0) {  // wave-uniform
         if (p.bias) bvs = p.bias[nc];
         if (p.pos_ptr) pos = *p.pos_ptr;
+        if (EPI == DE_LOGITS && p.mask) {
+            mword0 = p.mask[nc >> 5];
+            mword1 = p.mask[p.mask_words + (nc >> 5)];
+        }
         if (EPI == DE_RESID) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -281,7 +288,8 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
         if (EPI == DE_LOGITS) {
             // arg-max over [arg_first, arg_last], first maximal index wins (Whisper.swift:38)
             unsigned long long key = 0ull;
-            if (b < p.B && nvalid && n >= p.arg_first && n <= p.arg_last) key = argmax_key(v, n);
+            const unsigned mw = (pos == p.mask_first_pos) ? mword1 : mword0;  // zero when no filter is set
+            if (b < p.B && nvalid && n >= p.arg_first && n <= p.arg_last && !((mw >> (n & 31)) & 1u)) key = argmax_key(v, n);
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) {
                 const unsigned long long ok = __shfl_xor(key, o);
@@ -669,6 +677,7 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     p.out_f32 = a.out_f32; p.out_bf16 = a.out_bf16;
     p.kcache = a.kcache; p.vcache = a.vcache; p.pos_ptr = a.pos_ptr; p.n_ctx = a.n_ctx; p.n_head = a.n_head;
     p.ldo = a.ldo; p.tilemax = a.argmax; p.arg_first = a.arg_first; p.arg_last = a.arg_last;
+    p.mask = a.mask; p.mask_words = a.mask_words; p.mask_first_pos = a.mask_first_pos;
     int grid = (a.N + 15) / 16;
     p.n_tiles = grid;
     static const bool no_pf = getenv("WM_NO_PREFETCH") != nullptr;

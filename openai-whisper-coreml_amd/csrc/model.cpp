@@ -56,6 +56,38 @@ static int alloc_decode_buffers(WmModel *m, hipStream_t s) {
     WM_TRY(dalloc_t(m, &m->dresult, WM_DEC_MAXB, s));
     WM_TRY(dalloc_t(m, &m->dseq, (size_t)WM_DEC_MAXB * (D.n_text_ctx + 1), s));
     WM_TRY(dalloc_t(m, &m->dpos, 4, s));
+    WM_TRY(dalloc_t(m, &m->dmask, (size_t)2 * (m->vpad / 32), s));
+    WM_HIP(hipMemsetAsync(m->dmask, 0, (size_t)2 * (m->vpad / 32) * 4, s));
+    return WM_OK;
+}
+
+// SuppressTokens / SuppressBlank of openai-whisper's decoding.py as two bitmaps over the vocabulary.
+int wm_model_set_suppress(wm_ctx *ctx, const int32_t *ids, int n, const int32_t *first_ids, int n_first) {
+    WmModel *m = ctx->model;
+    WM_REQUIRE(m, WM_ERR_STATE, "context has no model");
+    WM_REQUIRE(n >= 0 && n_first >= 0 && (n == 0 || ids) && (n_first == 0 || first_ids), WM_ERR_INVALID,
+               "set_suppress: bad list");
+    const int words = m->vpad / 32, V = m->dims.n_vocab;
+    std::vector<unsigned> bits((size_t)2 * words, 0u);
+    for (int i = 0; i < n; ++i) {
+        WM_REQUIRE(ids[i] >= 0 && ids[i] < V, WM_ERR_INVALID, "set_suppress: token %d outside [0, %d)", ids[i], V);
+        bits[ids[i] >> 5] |= 1u << (ids[i] & 31);
+    }
+    for (int i = 0; i < words; ++i) bits[words + i] = bits[i];  // first position: always-list OR first-list
+    for (int i = 0; i < n_first; ++i) {
+        WM_REQUIRE(first_ids[i] >= 0 && first_ids[i] < V, WM_ERR_INVALID, "set_suppress: token %d outside [0, %d)",
+                   first_ids[i], V);
+        bits[words + (first_ids[i] >> 5)] |= 1u << (first_ids[i] & 31);
+    }
+    size_t live0 = 0, live1 = 0;
+    for (int t = 0; t < V; ++t) {
+        live0 += !((bits[t >> 5] >> (t & 31)) & 1u);
+        live1 += !((bits[words + (t >> 5)] >> (t & 31)) & 1u);
+    }
+    WM_REQUIRE(live0 > 0 && live1 > 0, WM_ERR_INVALID, "set_suppress: every token would be suppressed");
+    WM_HIP(hipMemcpyAsync(m->dmask, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
+    m->mask_on = (n + n_first) > 0;
     return WM_OK;
 }
 
@@ -182,6 +214,8 @@ int wm_model_clone(wm_ctx *child, const wm_ctx *parent) {
     m->tensors = pm->tensors; m->index = pm->index;   // registry for wm_get_tensor (pointers alias the parent)
     m->shares_weights = true;
     WM_TRY(alloc_decode_buffers(m, child->stream));
+    WM_HIP(hipMemcpyAsync(m->dmask, pm->dmask, (size_t)2 * (m->vpad / 32) * 4, hipMemcpyDeviceToDevice, child->stream));
+    m->mask_on = pm->mask_on;
     WM_HIP(hipStreamSynchronize(child->stream));
     return WM_OK;
 }
@@ -441,7 +475,7 @@ int wm_model_set_pos(wm_ctx *ctx, int pos) {
     return WM_OK;
 }
 
-int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, int arg_last) {
+int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, int arg_last, int mask_first_pos) {
     WmModel *m = ctx->model;
     const wm_dims &D = m->dims;
     const int d = D.n_text_state, H = D.n_text_head, T = D.n_text_ctx, S = 1500;
@@ -507,6 +541,9 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.x = m->dx; a.ln_g = m->ln_g; a.ln_b = m->ln_b; a.stats_in = m->dstats; a.stats_parts = parts;
         a.out_f32 = want_logits ? m->dlogits : nullptr; a.ldo = m->vpad;
         a.argmax = m->dargmax; a.arg_first = arg_first; a.arg_last = arg_last;
+        if (mask_first_pos >= 0) {
+            a.mask = m->dmask; a.mask_words = m->vpad / 32; a.mask_first_pos = mask_first_pos; a.pos_ptr = m->dpos;
+        }
         WM_TRY(wm_dec_gemv(ctx, a));
     }
     return WM_OK;

@@ -107,7 +107,9 @@ struct WmModel {
     // captured decode step (one hipGraph replayed for every position)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
-    int graph_B = 0, graph_n_prompt = 0, graph_cap_b = 0;
+    int graph_B = 0, graph_n_prompt = 0, graph_cap_b = 0, graph_mask = 0;
+    unsigned *dmask = nullptr;   // [2][vpad/32] suppressed-token bitmaps (wm_set_suppress); [1] = first generated token
+    bool mask_on = false;
     void *pcm_stage = nullptr;  // host-pointer staging for wm_transcribe_greedy
     size_t pcm_stage_bytes = 0;
     float *io_stage = nullptr;  // staging for host-pointer model calls
@@ -132,7 +134,9 @@ int wm_model_decode_begin(wm_ctx *ctx, int B);
 // embedded input of that position in m->dx (+ m->dstats): wm_model_embed_first for the first
 // position, afterwards produced by wm_model_close_step.  Ends with logits -> per-tile arg-max over
 // [arg_first, arg_last] (m->dargmax); want_logits additionally stores f32 logits in m->dlogits.
-int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, int arg_last);
+int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, int arg_last, int mask_first_pos = -1);
+// mask_first_pos >= 0: apply the suppress bitmaps, the first-token one at decode position mask_first_pos
+int wm_model_set_suppress(wm_ctx *ctx, const int32_t *ids, int n, const int32_t *first_ids, int n_first);
 int wm_model_embed_first(wm_ctx *ctx, int B);
 // arg-max reduce + write next token (positions >= n_prompt) + embed next position + advance *dpos
 int wm_model_close_step(wm_ctx *ctx, int B, int n_prompt, bool write_seq, int *result, int arg_first);
@@ -199,6 +203,10 @@ struct DecGemvArgs {
     long ldo;
     unsigned long long *argmax;  // DE_LOGITS: per-tile packed maxima [B][ceil(N/16)] over [arg_first, arg_last]
     int arg_first, arg_last;
+    // DE_LOGITS: suppressed-token bitmaps (bit n of word n/32), [2][mask_words]: [0] every position, [1] the position
+    // *pos_ptr == mask_first_pos only (first generated token); null = no filter
+    const unsigned *mask;
+    int mask_words, mask_first_pos;
     // optional L2 warm-up of the NEXT skinny GEMV's weights ([pf_rows][pf_k] bf16, WL_TILED)
     const bf16_t *pf_ptr;
     int pf_rows, pf_k;

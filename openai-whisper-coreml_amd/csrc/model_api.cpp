@@ -51,6 +51,13 @@ extern "C" int wm_finalize(wm_ctx *ctx) {
     (void)m;
     return wm_model_finalize(ctx);
 }
+extern "C" int wm_set_suppress(wm_ctx *ctx, const int32_t *suppress, int n, const int32_t *suppress_first, int n_first) {
+    WM_MODEL(ctx);
+    (void)m;
+    WM_TRY(wm_model_set_suppress(ctx, suppress, n, suppress_first, n_first));
+    for (wm_ctx *lane : ctx->lanes) WM_TRY(wm_model_set_suppress(lane, suppress, n, suppress_first, n_first));
+    return WM_OK;
+}
 extern "C" int wm_get_dims(const wm_ctx *ctx, wm_dims *out) {
     WM_REQUIRE(ctx && out, WM_ERR_INVALID, "null pointer");
     WM_REQUIRE(ctx->model, WM_ERR_STATE, "context has no model");
@@ -299,18 +306,20 @@ int lane_prefill(LaneJob &j, const void *pcm, wm_dtype pcm_dtype, const int32_t 
 int lane_graph(LaneJob &j, int n_prompt) {
     wm_ctx *c = j.c;
     WmModel *m = c->model;
-    if (m->graph_exec && m->graph_B == j.Bg && m->graph_n_prompt == n_prompt && m->graph_cap_b == m->cap_b)
+    const int mk = m->mask_on ? 1 : 0;
+    if (m->graph_exec && m->graph_B == j.Bg && m->graph_n_prompt == n_prompt && m->graph_cap_b == m->cap_b &&
+        m->graph_mask == mk)
         return WM_OK;
     if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
     if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
     WM_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    int crc = wm_model_decode_step(c, j.Bg, false, 0, m->dims.n_vocab - 1);
+    int crc = wm_model_decode_step(c, j.Bg, false, 0, m->dims.n_vocab - 1, m->mask_on ? n_prompt - 1 : -1);
     if (crc == WM_OK) crc = wm_model_close_step(c, j.Bg, n_prompt, true, nullptr, 0);
     hipError_t ce = hipStreamEndCapture(c->stream, &m->graph);
     if (crc != WM_OK) return crc;
     WM_HIP(ce);
     WM_HIP(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
-    m->graph_B = j.Bg; m->graph_n_prompt = n_prompt; m->graph_cap_b = m->cap_b;
+    m->graph_B = j.Bg; m->graph_n_prompt = n_prompt; m->graph_cap_b = m->cap_b; m->graph_mask = mk;
     return WM_OK;
 }
 }  // namespace
@@ -371,7 +380,8 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
                 if (use_graph) {
                     WM_HIP(hipGraphLaunch(j.c->model->graph_exec, j.c->stream));
                 } else {
-                    WM_TRY(wm_model_decode_step(j.c, j.Bg, false, 0, D.n_vocab - 1));
+                    WM_TRY(wm_model_decode_step(j.c, j.Bg, false, 0, D.n_vocab - 1,
+                                                j.c->model->mask_on ? n_prompt - 1 : -1));
                     WM_TRY(wm_model_close_step(j.c, j.Bg, n_prompt, true, nullptr, 0));
                 }
             }

@@ -111,9 +111,11 @@ def detect_language(sd, dims, xa, sot=50258, lang_first=50259, lang_last=50357):
 
 
 @torch.no_grad()
-def greedy(sd, dims, xa, prompt, max_new, eot=-1):
+def greedy(sd, dims, xa, prompt, max_new, eot=-1, suppress=(), suppress_first=()):
     """KV-cached greedy decode (the extension BASELINE.json asks for): returns tokens
-    [B, max_new] (padded with eot after a stop), lens [B], and the per-step logits."""
+    [B, max_new] (padded with eot after a stop), lens [B], and the per-step logits (filtered).
+    `suppress` / `suppress_first` restate openai-whisper's SuppressTokens / SuppressBlank logit filters
+    (whisper/decoding.py [3p]: logits[:, ids] = -inf, the blank filter only at the first sampled position)."""
     xa = torch.as_tensor(xa, dtype=torch.float32)
     B = xa.shape[0]
     L, H = dims["n_text_layer"], dims["n_text_head"]
@@ -156,6 +158,10 @@ def greedy(sd, dims, xa, prompt, max_new, eot=-1):
             x = x + _linear(hh, sd, p + ".mlp.2")
         x = _ln(x[:, -1:], sd, "decoder.ln")
         logits = (x @ sd["decoder.token_embedding.weight"].T).float()[:, 0]
+        if len(suppress):
+            logits[:, list(suppress)] = float("-inf")
+        if step == 0 and len(suppress_first):
+            logits[:, list(suppress_first)] = float("-inf")
         all_logits.append(logits.numpy())
         nxt = logits.argmax(dim=1)
         for b in range(B):

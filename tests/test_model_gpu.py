@@ -441,3 +441,48 @@ def test_large_call_is_spread_over_lanes(lively):
     got16, _ = ctx.transcribe_greedy(s16, prompt, 12)
     solo16, _ = ctx.transcribe_greedy(s16[:7], prompt, 12)
     assert np.array_equal(got16[:7], solo16) and np.array_equal(got16[7:13], ctx.transcribe_greedy(s16[7:13], prompt, 12)[0])
+
+
+def test_suppress_filters_follow_the_oracle(lively, pkg):
+    """wm_set_suppress == openai-whisper's SuppressTokens + SuppressBlank inside the fused logits / arg-max kernel."""
+    dims, _, sd, ctx = lively
+    pcm = tones(3)
+    mel = ctx.logmel(pcm, out_dtype=np.float32)
+    prompt = [10, 21, 5]
+    free, _ = ctx.transcribe_greedy(pcm, prompt, 12)
+    # forbid everything the unfiltered run produced, plus the runner-up of its first choice at the first position only
+    banned = sorted({int(t) for t in free.ravel()})
+    xa = ctx.encode_mel(mel)
+    first_logits = R.decode_logits(sd, dims, np.tile(prompt, (3, 1)), xa).numpy()[:, -1]
+    first_logits[:, banned] = -np.inf
+    banned_first = sorted({int(np.argmax(r)) for r in first_logits})
+    ctx.set_suppress(banned, banned_first)
+    try:
+        got, lens = ctx.transcribe_greedy(pcm, prompt, 12)
+        assert not (set(got.ravel().tolist()) & set(banned))
+        assert not (set(got[:, 0].tolist()) & set(banned_first))
+        want, _, logits = R.greedy(sd, dims, R.encode(sd, dims, mel), prompt, 12, suppress=banned, suppress_first=banned_first)
+        for b in range(3):
+            seq = np.concatenate([prompt, got[b]])[None, :-1]
+            ref = R.decode_logits(sd, dims, seq, xa[b:b + 1]).numpy()[0]
+            for i in range(12):
+                row = ref[len(prompt) - 1 + i].copy()
+                row[banned] = -np.inf
+                if i == 0:
+                    row[banned_first] = -np.inf
+                _check_choice(row, int(got[b, i]))
+            for i in range(12):                       # free-running agreement up to the first near-tie
+                top2 = np.sort(logits[b, i][np.isfinite(logits[b, i])])[-2:]
+                if top2[1] - top2[0] < MARGIN:
+                    break
+                assert got[b, i] == want[b, i], (b, i)
+        # a 19-chunk call runs on the lanes: they carry the same filter
+        idx = [i % 3 for i in range(19)]
+        many, _ = ctx.transcribe_greedy(pcm[idx], prompt, 12)
+        assert np.array_equal(many, got[idx])
+        with pytest.raises(pkg.binding.WhisperError, match="outside"):
+            ctx.set_suppress([dims["n_vocab"]], [])
+    finally:
+        ctx.set_suppress([], [])
+    again, _ = ctx.transcribe_greedy(pcm, prompt, 12)
+    assert np.array_equal(again, free)

@@ -69,6 +69,22 @@ def test_kv_cached_greedy_equals_full_recompute():
     assert conf.shape == (1, 99) and idx[0] == int(conf[0].argmax())
 
 
+def test_suppress_filters_in_the_oracle():
+    """SuppressTokens / SuppressBlank restatement: banned ids get -inf (the blank list only at the first position)."""
+    dims = dict(R.TINY_DIMS)
+    sd = R.to_torch(_sd(4))
+    mel = np.random.default_rng(2).standard_normal((1, 80, 3000)).astype(np.float32) * 0.5
+    xa = R.encode(sd, dims, mel)
+    free, _, _ = R.greedy(sd, dims, xa, [1, 2], 6)
+    banned = sorted(set(free[0].tolist()))
+    got, _, logits = R.greedy(sd, dims, xa, [1, 2], 6, suppress=banned, suppress_first=[7])
+    assert not (set(got[0].tolist()) & set(banned)) and got[0, 0] != 7
+    assert np.isneginf(logits[0, 0, 7]) and not np.isneginf(logits[0, 1, 7])
+    assert all(np.isneginf(logits[0, :, b]).all() for b in banned)
+    same, _, _ = R.greedy(sd, dims, xa, [1, 2], 6, suppress=(), suppress_first=())
+    assert np.array_equal(same, free)
+
+
 def test_model_golden_vectors():
     """Committed fixture (tests/golden/make_model_golden.py): pins the oracle against drift."""
     g = np.load(os.path.join(GOLDEN, "model_golden.npz"))
