@@ -28,14 +28,18 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+// f32 -> bf16 round-to-nearest-even: v_cvt_pk_bf16_f32 on gfx950
 __device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    const __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, h);
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
 __device__ __forceinline__ unsigned pack2(float a, float b) {
-    return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -201,33 +205,43 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
             const float mean = s1 / (float)p.K;
             float var = s2 / (float)p.K - mean * mean;
             var = var > 0.f ? var : 0.f;
-            if (lane < 16) *(float2 *)(st + lane * 2) = make_float2(mean, rsqrtf(var + 1e-5f));
+            const float rstd = rsqrtf(var + 1e-5f);
+            if (lane < 16) *(float2 *)(st + lane * 2) = make_float2(rstd, -mean * rstd);  // y = x*rstd - mean*rstd
         }
-        for (int b0 = 0; b0 < p.B; b0 += 8) {  // wave-uniform: 1 trip (B <= 8) or 2
-            if (b0 > 0) {
+        // rows 8..15 (B > 8, wave-uniform): requested as soon as the statistics registers are free, BEFORE the first
+        // eight rows are normalised, so the prologue still has a single activation round trip on its critical path
+        float4 xw[8][2];
+        if (p.B > 8) {
 #pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const int bc = b0 + b < p.B ? b0 + b : p.B - 1;
+            for (int b = 0; b < 8; ++b) {
+                const int bc = 8 + b < p.B ? 8 + b : p.B - 1;
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        xv[b][u] = *(const float4 *)(p.x + (long)bc * p.K + kbase + 4 * j4c[u]);
-                }
+                for (int u = 0; u < 2; ++u) xw[b][u] = *(const float4 *)(p.x + (long)bc * p.K + kbase + 4 * j4c[u]);
             }
+        }
+        // normalise: t = x*rstd + (-mean*rstd), y = t*g + b, as packed f32 FMAs; bf16 pairs by v_cvt_pk_bf16_f32
+        auto apply = [&](const float4 (&xr)[8][2], int b0) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const int br = b0 + b < p.B ? b0 + b : p.B - 1;  // duplicates rewrite row B-1 with equal data
                 const float2 ms = *(const float2 *)(st + br * 2);
+                const f32x2 a2 = {ms.x, ms.x}, c2 = {ms.y, ms.y};
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const unsigned lo = pack2((xv[b][u].x - ms.x) * ms.y * gv[u].x + bv[u].x,
-                                              (xv[b][u].y - ms.x) * ms.y * gv[u].y + bv[u].y);
-                    const unsigned hi = pack2((xv[b][u].z - ms.x) * ms.y * gv[u].z + bv[u].z,
-                                              (xv[b][u].w - ms.x) * ms.y * gv[u].w + bv[u].w);
+                    const f32x2 x01 = {xr[b][u].x, xr[b][u].y}, x23 = {xr[b][u].z, xr[b][u].w};
+                    const f32x2 g01 = {gv[u].x, gv[u].y}, g23 = {gv[u].z, gv[u].w};
+                    const f32x2 b01 = {bv[u].x, bv[u].y}, b23 = {bv[u].z, bv[u].w};
+                    const f32x2 y01 = __builtin_elementwise_fma(__builtin_elementwise_fma(x01, a2, c2), g01, b01);
+                    const f32x2 y23 = __builtin_elementwise_fma(__builtin_elementwise_fma(x23, a2, c2), g23, b23);
+                    const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(y01, bf16x2));
+                    const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(y23, bf16x2));
                     // clamped column: lanes past the chunk rewrite column kc4-1 with equal data
                     *(uint2 *)(xs + br * xs_stride + j4c[u] * 8) = make_uint2(lo, hi);
                 }
             }
-        }
+        };
+        apply(xv, 0);
+        if (p.B > 8) apply(xw, 8);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
@@ -387,15 +401,20 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const float *__restrict_
                                                         int T_stride, int n_keys_const,
                                                         const int *__restrict__ pos_ptr, int nsplit,
                                                         float *__restrict__ part, bf16_t *__restrict__ att,
-                                                        int n_bh, const char *pf_ptr, long pf_tile_bytes) {
-    if ((int)blockIdx.x >= n_bh) {  // L2 warm-up workgroup for the next GEMV's weights (see l2_warm_tile)
-        l2_warm_tile(pf_ptr, pf_tile_bytes, (int)blockIdx.x - n_bh, 1024);
+                                                        int n_bh, int n_wg, const char *pf_ptr,
+                                                        long pf_tile_bytes) {
+    if ((int)blockIdx.x >= n_wg) {  // L2 warm-up workgroup for the next GEMV's weights (see l2_warm_tile)
+        l2_warm_tile(pf_ptr, pf_tile_bytes, (int)blockIdx.x - n_wg, 1024);
         return;
     }
     __shared__ float wred[ATT_NW];
     __shared__ float wl[ATT_NW];
     __shared__ float wacc[ATT_NW][64];
-    const int bh = blockIdx.x, b = bh / H, h = bh % H, sp = blockIdx.y;
+    // n_wg <= n_bh compute workgroups walk the (sequence, head) pairs: a workgroup of this kernel owns its CU's whole
+    // register file, so capping the grid is what leaves CUs to the kernels of the other decode groups in flight.
+    for (int bh = blockIdx.x; bh < n_bh; bh += n_wg) {
+    if (bh != (int)blockIdx.x) __syncthreads();  // the previous pair's LDS reductions have been read
+    const int b = bh / H, h = bh % H, sp = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rg = lane >> 3, e8 = lane & 7;
     const int n_keys = pos_ptr ? (*pos_ptr + 1) : n_keys_const;
@@ -501,6 +520,7 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const float *__restrict_
             }
         }
     }
+    }  // (sequence, head) pairs of this workgroup
 }
 
 // Combine flash-decoding partials -> bf16 head outputs.  grid B*H, 64 threads.
@@ -744,7 +764,16 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
     {
         WmProfScope ps(&ctx->prof, cross ? "dec_attn_cross" : "dec_attn_self", ctx->stream);
         static const bool no_pf = getenv("WM_NO_PREFETCH") != nullptr;
-        int gx = B * H;
+        // Compute workgroups: one per (sequence, head) up to a cap (default 160 = what B = 8 x 20 heads uses; measured:
+        // more than that blocks the CUs the other decode groups need).  WM_XATTN_WGS overrides (A/B probes).
+        static const int env_cap = getenv("WM_XATTN_WGS") ? atoi(getenv("WM_XATTN_WGS")) : 0;
+        const int cap = env_cap > 0 ? env_cap : 160;
+        int n_wg = B * H;
+        if (cross && nsplit == 1 && n_wg > cap) {
+            const int rounds = (n_wg + cap - 1) / cap;
+            n_wg = (n_wg + rounds - 1) / rounds;  // balanced: every workgroup walks `rounds` (or rounds - 1) pairs
+        }
+        int gx = n_wg;
         long tile_bytes = 0;
         if (!no_pf && pf_ptr && nsplit == 1 && gx % 8 == 0 && pf_rows >= 16) {
             tile_bytes = 16L * pf_k * 2;
@@ -755,10 +784,10 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
         const int per_wg = ((max_keys + nsplit - 1) / nsplit + 7) & ~7;
         if (per_wg <= 4 * ATT_NW * 8)
             dec_attn_kernel<4><<<grid, 1024, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, nsplit,
-                                                              part, att, B * H, (const char *)pf_ptr, tile_bytes);
+                                                              part, att, B * H, n_wg, (const char *)pf_ptr, tile_bytes);
         else
             dec_attn_kernel<12><<<grid, 1024, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, nsplit,
-                                                               part, att, B * H, (const char *)pf_ptr, tile_bytes);
+                                                               part, att, B * H, n_wg, (const char *)pf_ptr, tile_bytes);
         WM_HIP(hipGetLastError());
     }
     if (nsplit > 1) {
