@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent batches kept in flight per GPU (each on its own HIP stream / context clone)")
     ap.add_argument("--fuse", type=int, default=2,
-                    help="consecutive steps (batches) decoded together as ONE group of fuse*batch chunks (<= 16): the "
+                    help="consecutive steps (batches) decoded together as ONE group of fuse*batch chunks (<= 32): the "
                          "decoder weights are streamed once per group and position")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -183,7 +183,7 @@ def main():
     ctx.finalize()
 
     nb = args.batch
-    F = max(1, min(args.fuse, 16 // nb if nb <= 16 else 1))
+    F = max(1, min(args.fuse, 32 // nb if nb <= 32 else 1))
     chunks = [structured_pcm16() if i == 0 else synth_pcm16(rank * nb * F + i) for i in range(nb * F)]
     pcm = np.stack(chunks)
     d_pcm = ctx.to_device(pcm)

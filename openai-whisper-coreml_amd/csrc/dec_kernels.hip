@@ -57,6 +57,7 @@ struct DecGemvDev {
     const float *x, *ln_g, *ln_b;
     const float *stats_in;  // DA_LN: [stats_parts][16][2] partial (sum x, sum x^2) per row
     int stats_parts;
+    long stats_stride;      // floats between the statistics of consecutive 16-row batch blocks (blockIdx.y)
     float *stats_out;       // DE_RESID: this launch's per-tile partials of the UPDATED residual
     const bf16_t *a_bf16;
     float *out_f32;
@@ -109,9 +110,25 @@ template <int AMODE, int EPI, int NW>
 __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x >= p.n_tiles) {  // workgroup-uniform
-        l2_warm_tile(p.pf_ptr, p.pf_tile_bytes, (int)blockIdx.x - p.n_tiles, NW * 64);
+        if (blockIdx.y == 0) l2_warm_tile(p.pf_ptr, p.pf_tile_bytes, (int)blockIdx.x - p.n_tiles, NW * 64);
         return;
     }
+    // Batches above 16 run as blockIdx.y blocks of 16 rows (the MFMA's M): same weight tile, so the second block's
+    // weight reads hit the L2 the first one filled (n_tiles % 8 == 0 puts both on one XCD) -- one HBM stream for all rows.
+    if (blockIdx.y != 0) {  // workgroup-uniform: rebase every per-row pointer of the by-value argument block
+        const long r0 = (long)blockIdx.y * 16;
+        if (p.x) p.x += r0 * p.K;
+        if (p.a_bf16) p.a_bf16 += r0 * p.K;
+        if (p.out_f32) p.out_f32 += r0 * (EPI == DE_QKV ? (long)(p.N / 3) : p.ldo);
+        if (p.out_bf16) p.out_bf16 += r0 * p.ldo;
+        if (p.kcache) p.kcache += r0 * p.n_head * p.n_ctx * 64;
+        if (p.vcache) p.vcache += r0 * p.n_head * p.n_ctx * 64;
+        if (p.stats_in) p.stats_in += (long)blockIdx.y * p.stats_stride;
+        if (p.stats_out) p.stats_out += (long)blockIdx.y * p.stats_stride;
+        if (p.tilemax) p.tilemax += r0 * p.n_tiles;
+        p.B -= (int)r0;
+    }
+    if (p.B > 16) p.B = 16;
     float *red = (float *)smem;
     float *part = red + NW * 256;
     char *xs_all = (char *)(part + 2 * NW * 16);
@@ -376,7 +393,8 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int *__restrict__ 
     __syncthreads();
     // LayerNorm partial statistics of this row: a single part (index 0)
     if (threadIdx.x == 0 && stats_out)
-        *(float2 *)(stats_out + b * 2) = make_float2((r1[0] + r1[1]) + (r1[2] + r1[3]), (r2[0] + r2[1]) + (r2[2] + r2[3]));
+        *(float2 *)(stats_out + (long)(b >> 4) * (2 * d) + (b & 15) * 2) =  // block of 16 rows: [parts][16][2]
+            make_float2((r1[0] + r1[1]) + (r1[2] + r1[3]), (r2[0] + r2[1]) + (r2[2] + r2[3]));
 }
 
 // ------------------------------------------------------------------ single-query attention
@@ -553,11 +571,11 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
                                                              const bf16_t *__restrict__ emb,
                                                              const float *__restrict__ pemb, int d, int n_ctx,
                                                              float *__restrict__ x, float *__restrict__ stats_out) {
-    __shared__ int tok_s[16];
+    __shared__ int tok_s[WM_DEC_MAXB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pos = pos_ptr ? *pos_ptr : 0;
-    if (wave < B) {
-        const unsigned long long *row = tilemax + (long)wave * n_tiles;
+    for (int b = wave; b < B; b += 16) {  // wave-uniform: one row per wave up to B = 16, two up to 32
+        const unsigned long long *row = tilemax + (long)b * n_tiles;
         unsigned long long key = 0ull;
         for (int t0 = lane; t0 < n_tiles; t0 += 64 * 8) {
             unsigned long long k[8];
@@ -578,29 +596,32 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
             const int tok = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
             int nxt = tok;
             if (seq) {
-                if (pos + 1 >= n_prompt) seq[(pos + 1) * B + wave] = tok;
-                else nxt = seq[(pos + 1) * B + wave];
+                if (pos + 1 >= n_prompt) seq[(pos + 1) * B + b] = tok;
+                else nxt = seq[(pos + 1) * B + b];
             }
-            tok_s[wave] = nxt;
-            if (result) result[wave] = tok - arg_first;
+            tok_s[b] = nxt;
+            if (result) result[b] = tok - arg_first;
         }
     }
     __syncthreads();
-    if (x && wave < B && pos + 1 < n_ctx) {
-        const long tok = tok_s[wave];
-        float s1 = 0.f, s2 = 0.f;
-        for (int j = lane; j < d; j += 64) {
-            const float v = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)(pos + 1) * d + j];
-            x[(long)wave * d + j] = v;
-            s1 += v;
-            s2 += v * v;
-        }
+    if (x && pos + 1 < n_ctx) {
+        for (int b = wave; b < B; b += 16) {
+            const long tok = tok_s[b];
+            float s1 = 0.f, s2 = 0.f;
+            for (int j = lane; j < d; j += 64) {
+                const float v = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)(pos + 1) * d + j];
+                x[(long)b * d + j] = v;
+                s1 += v;
+                s2 += v * v;
+            }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            s1 += __shfl_xor(s1, o);
-            s2 += __shfl_xor(s2, o);
+            for (int o = 32; o > 0; o >>= 1) {
+                s1 += __shfl_xor(s1, o);
+                s2 += __shfl_xor(s2, o);
+            }
+            if (lane == 0 && stats_out)
+                *(float2 *)(stats_out + (long)(b >> 4) * (2 * d) + (b & 15) * 2) = make_float2(s1, s2);
         }
-        if (lane == 0 && stats_out) *(float2 *)(stats_out + wave * 2) = make_float2(s1, s2);
     }
     if (threadIdx.x == 0 && pos_ptr) *pos_ptr = pos + 1;
 }
@@ -647,11 +668,13 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(void *dst, int is_bf16,
 }
 
 template <int AMODE, int EPI>
-int launch_gemv_b(wm_ctx *ctx, const DecGemvDev &p, int nw, int grid) {
+int launch_gemv_b(wm_ctx *ctx, const DecGemvDev &p, int nw, int gx) {
     hipStream_t s = ctx->stream;
+    const int bb = p.B < 16 ? p.B : 16;  // rows per batch block; blocks of 16 rows are blockIdx.y
     size_t lds = (size_t)nw * 1024 + 2 * nw * 16 * 4;
-    if (AMODE == DA_LN) lds += (size_t)nw * p.B * (p.KC + 8) * 2;
+    if (AMODE == DA_LN) lds += (size_t)nw * bb * (p.KC + 8) * 2;
     lds = (lds + 15) & ~(size_t)15;
+    const dim3 grid(gx, (p.B + 15) / 16);
     switch (nw) {
         case 1: dec_gemv_kernel<AMODE, EPI, 1><<<grid, 64, lds, s>>>(p); break;
         case 2: dec_gemv_kernel<AMODE, EPI, 2><<<grid, 128, lds, s>>>(p); break;
@@ -694,6 +717,7 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     p.B = a.B; p.N = a.N; p.K = a.K; p.KC = a.K / nw;
     p.W = a.W; p.bias = a.bias; p.x = a.x; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.a_bf16 = a.a_bf16;
     p.stats_in = a.stats_in; p.stats_parts = a.stats_parts; p.stats_out = a.stats_out;
+    p.stats_stride = 2L * (a.epi == DE_RESID ? a.N : a.K);  // [parts <= d/16][16][2] floats per block of 16 rows
     p.out_f32 = a.out_f32; p.out_bf16 = a.out_bf16;
     p.kcache = a.kcache; p.vcache = a.vcache; p.pos_ptr = a.pos_ptr; p.n_ctx = a.n_ctx; p.n_head = a.n_head;
     p.ldo = a.ldo; p.tilemax = a.argmax; p.arg_first = a.arg_first; p.arg_last = a.arg_last;

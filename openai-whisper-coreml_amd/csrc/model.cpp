@@ -49,7 +49,7 @@ static int alloc_decode_buffers(WmModel *m, hipStream_t s) {
     WM_TRY(dalloc_t(m, &m->dq, (size_t)WM_DEC_MAXB * d, s));
     WM_TRY(dalloc_t(m, &m->dpart, (size_t)WM_DEC_MAXB * D.n_text_head * WM_MAXSPLIT * 66, s));
     WM_TRY(dalloc_t(m, &m->datt, (size_t)WM_DEC_MAXB * d, s));
-    WM_TRY(dalloc_t(m, &m->dstats, (size_t)(d / 16) * 16 * 2, s));
+    WM_TRY(dalloc_t(m, &m->dstats, (size_t)(WM_DEC_MAXB / 16) * (d / 16) * 16 * 2, s));
     WM_TRY(dalloc_t(m, &m->dhid, (size_t)WM_DEC_MAXB * 4 * d, s));
     WM_TRY(dalloc_t(m, &m->dlogits, (size_t)WM_DEC_MAXB * m->vpad, s));
     WM_TRY(dalloc_t(m, &m->dargmax, (size_t)WM_DEC_MAXB * (m->vpad / 16), s));

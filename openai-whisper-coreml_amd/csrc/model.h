@@ -96,7 +96,7 @@ struct WmModel {
     float *dx = nullptr;        // [16][d]   decoder residual stream
     float *dq = nullptr;        // [16][d]   query (self or cross)
     float *dpart = nullptr;     // [16][H][WM_MAXSPLIT][66] attention partials (m, l, o[64])
-    float *dstats = nullptr;    // [d/16][16][2] LayerNorm partial statistics of the residual stream
+    float *dstats = nullptr;    // [B/16][d/16][16][2] LayerNorm partial statistics of the residual stream
     bf16_t *datt = nullptr;     // [16][d]   attention head outputs (bf16 A operand of the out-projection)
     bf16_t *dhid = nullptr;     // [16][4d]
     float *dlogits = nullptr;   // [B][vpad]
@@ -178,7 +178,7 @@ int wm_enc_attention(wm_ctx *ctx, const bf16_t *qk, const bf16_t *vt, bf16_t *at
                      int S, int S_pad, int d);
 
 // dec_kernels.hip
-constexpr int WM_DEC_MAXB = 16;
+constexpr int WM_DEC_MAXB = 32;  // decode group: two batch blocks of 16 rows (the MFMA M dimension)
 constexpr int WM_MAXSPLIT = 8;  // flash-decoding splits of single-query attention (small batches)
 enum DecAMode { DA_LN = 0, DA_BF16 = 1 };
 enum DecEpi { DE_QKV = 0, DE_Q = 1, DE_RESID = 2, DE_GELU = 3, DE_LOGITS = 4 };

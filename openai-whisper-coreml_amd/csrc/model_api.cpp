@@ -235,7 +235,7 @@ static size_t pcm_elem(wm_dtype t) { return t == WM_I16 ? 2 : t == WM_F32 ? 4 : 
 // clones of the context (wm_clone), each with its own stream, activations, KV caches and decode graph.  The
 // single host thread enqueues the lanes round-robin; the GPU overlaps them.
 namespace {
-constexpr int kGroupChunks = 8;   // preferred chunks per decode group (BASELINE.json configs[3])
+constexpr int kGroupChunks = 8;   // smallest decode group worth a lane (BASELINE.json configs[3]); up to WM_DEC_MAXB
 
 int lane_limit() {
     static const int n = [] {
@@ -532,6 +532,7 @@ extern "C" int wmdbg_enc_attention(wm_ctx *ctx, const float *q, const float *k, 
 extern "C" int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, const float *ln_b, const float *W,
                               const float *bias, float *out, int B, int N, int K) {
     WM_TRY(wm_ctx_make_current(ctx));
+    WM_REQUIRE(B >= 1 && B <= 16, WM_ERR_INVALID, "wmdbg_dec_gemv: one batch block (B <= 16)");
     const int Npad = ((N + 15) / 16) * 16;
     std::vector<bf16_t> w16, x16;
     std::vector<float> wp((size_t)Npad * K, 0.f);   // fragment-tiled order (WL_TILED)
@@ -618,21 +619,22 @@ void wm_dec_gemv_set_waves_override(int nw);
 extern "C" int wmdbg_bench_dec_gemv(wm_ctx *ctx, int B, int N, int K, int ln, int resid, int n_mats, int iters,
                                     int nw_override, float *avg_us) {
     WM_TRY(wm_ctx_make_current(ctx));
+    WM_REQUIRE(B >= 1 && B <= WM_DEC_MAXB, WM_ERR_INVALID, "wmdbg_bench_dec_gemv: B out of range");
     hipStream_t s = ctx->stream;
     const int Npad = ((N + 15) / 16) * 16;
     void *dW, *dx, *dx16, *dg, *db, *dout;
     WM_TRY(up(&dW, nullptr, (size_t)n_mats * Npad * K * 2, s));
-    WM_TRY(up(&dx, nullptr, (size_t)16 * K * 4, s));
-    WM_TRY(up(&dx16, nullptr, (size_t)16 * K * 2, s));
+    WM_TRY(up(&dx, nullptr, (size_t)WM_DEC_MAXB * K * 4, s));
+    WM_TRY(up(&dx16, nullptr, (size_t)WM_DEC_MAXB * K * 2, s));
     WM_TRY(up(&dg, nullptr, (size_t)K * 4, s));
     WM_TRY(up(&db, nullptr, (size_t)K * 4, s));
-    WM_TRY(up(&dout, nullptr, (size_t)16 * Npad * 4, s));
+    WM_TRY(up(&dout, nullptr, (size_t)WM_DEC_MAXB * Npad * 4, s));
     WM_HIP(hipMemsetAsync(dW, 0x3c, (size_t)n_mats * Npad * K * 2, s));
     DecGemvArgs a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.N = N; a.K = K; a.out_f32 = (float *)dout; a.ldo = Npad; a.epi = resid ? DE_RESID : DE_Q;
     void *dstat;
-    WM_TRY(up(&dstat, nullptr, (size_t)(K / 16 + 1) * 16 * 2 * 4, s));
+    WM_TRY(up(&dstat, nullptr, (size_t)(WM_DEC_MAXB / 16) * 2 * (K > N ? K : N) * 4 + 4096, s));
     if (resid) a.stats_out = (float *)dstat;
     if (ln) { a.a_mode = DA_LN; a.x = (const float *)dx; a.ln_g = (const float *)dg; a.ln_b = (const float *)db;
               a.stats_in = (const float *)dstat; a.stats_parts = K / 16; }

@@ -486,3 +486,20 @@ def test_suppress_filters_follow_the_oracle(lively, pkg):
         ctx.set_suppress([], [])
     again, _ = ctx.transcribe_greedy(pcm, prompt, 12)
     assert np.array_equal(again, free)
+
+
+def test_decode_groups_above_sixteen_use_two_batch_blocks(lively):
+    """A decode group of 17..32 chunks runs every skinny GEMM as two blocks of 16 batch rows in one launch; every
+    chunk must still decode exactly as it does alone (90 chunks -> 3 lanes x 30)."""
+    dims, _, _, ctx = lively
+    base = tones(7)
+    prompt = [10, 21, 5]
+    want, _ = ctx.transcribe_greedy(base, prompt, 12)
+    for B in (17, 32):
+        idx = [(3 * i + 2) % 7 for i in range(B)]
+        got = ctx.detect_language(ctx.encode_mel(ctx.logmel(base[idx], out_dtype=np.float32)), sot=10, lang_first=20, lang_last=118)
+        one = ctx.detect_language(ctx.encode_mel(ctx.logmel(base, out_dtype=np.float32)), sot=10, lang_first=20, lang_last=118)
+        assert np.array_equal(got, one[idx]), B           # wm_detect_language at B > 16 (one decode step)
+    idx = [(5 * i + 1) % 7 for i in range(90)]
+    got, lens = ctx.transcribe_greedy(base[idx], prompt, 12)
+    assert np.array_equal(got, want[idx]) and np.all(lens == 12)
