@@ -110,7 +110,8 @@ template <int AMODE, int EPI, int NW>
 __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x >= p.n_tiles) {  // workgroup-uniform
-        if (blockIdx.y == 0) l2_warm_tile(p.pf_ptr, p.pf_tile_bytes, (int)blockIdx.x - p.n_tiles, NW * 64);
+        if (blockIdx.y == 0 && (int)blockIdx.x - p.n_tiles < p.pf_tiles)
+            l2_warm_tile(p.pf_ptr, p.pf_tile_bytes, (int)blockIdx.x - p.n_tiles, NW * 64);
         return;
     }
     // Batches above 16 run as blockIdx.y blocks of 16 rows (the MFMA's M): same weight tile, so the second block's
@@ -541,6 +542,121 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const float *__restrict_
     }  // (sequence, head) pairs of this workgroup
 }
 
+// ------------------------------------------------------------------ causal self-attention (decode)
+// The self-attention cache holds <= 448 rows and ~115 on average over a 224-token decode: a (sequence, head) pair
+// is 15-57 KB, far too little for the 16-wave streaming kernel above (its workgroups fill the chip 2 per CU, and at
+// 32 sequences x 20 heads they need two rounds).  Here a pair is ONE 4-wave workgroup (8 resident per CU): the waves
+// walk the rows in blocks of 128 (4 waves x 8 rows x 4 loads; K and V of a block requested together), each wave
+// keeps its own running (max, sum, o[64]) -- no workgroup barrier inside the loop -- and the four partial results
+// are merged once through LDS.  fp32 softmax, bf16 head output, same row -> lane mapping as dec_attn_kernel.
+constexpr int SAT_NW = 4, SAT_U = 4;
+__global__ __launch_bounds__(SAT_NW * 64) void dec_self_attn_kernel(const float *__restrict__ q,
+                                                                    const bf16_t *__restrict__ kc,
+                                                                    const bf16_t *__restrict__ vc, int H, int d,
+                                                                    int T_stride, int n_keys_const,
+                                                                    const int *__restrict__ pos_ptr,
+                                                                    bf16_t *__restrict__ att, int n_bh,
+                                                                    const char *pf_ptr, long pf_tile_bytes) {
+    if ((int)blockIdx.x >= n_bh) {  // L2 warm-up workgroup for the next GEMV's weights
+        l2_warm_tile(pf_ptr, pf_tile_bytes, (int)blockIdx.x - n_bh, SAT_NW * 64);
+        return;
+    }
+    __shared__ float wm_[SAT_NW], wl_[SAT_NW];
+    __shared__ float wo_[SAT_NW][64];
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rg = lane >> 3, e8 = lane & 7;
+    const int n_keys = pos_ptr ? (*pos_ptr + 1) : n_keys_const;
+    const int last = n_keys - 1;
+    const bf16_t *kb = kc + (long)bh * T_stride * 64 + e8 * 8;
+    const bf16_t *vb = vc + (long)bh * T_stride * 64 + e8 * 8;
+    float qe[8];
+    {
+        const float *qp = q + (long)b * d + h * 64 + e8 * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qe[i] = qp[i] * 0.125f;  // hd^-0.5
+    }
+    float m_run = -1e30f, l_run = 0.f;
+    float oa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r0 = 0; r0 < n_keys; r0 += SAT_NW * 8 * SAT_U) {  // workgroup-uniform trip count
+        u32x4 kv[SAT_U], vv[SAT_U];
+#pragma unroll
+        for (int u = 0; u < SAT_U; ++u) {
+            int i = r0 + u * (SAT_NW * 8) + wave * 8 + rg;
+            i = i < n_keys ? i : last;  // clamped: unconditional loads
+            kv[u] = *(const u32x4 *)(kb + (long)i * 64);
+            vv[u] = *(const u32x4 *)(vb + (long)i * 64);
+        }
+        float sc[SAT_U];
+        float mb = -1e30f;
+#pragma unroll
+        for (int u = 0; u < SAT_U; ++u) {
+            const int i = r0 + u * (SAT_NW * 8) + wave * 8 + rg;
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a += qe[2 * j] * __uint_as_float(kv[u][j] << 16);
+                a += qe[2 * j + 1] * __uint_as_float(kv[u][j] & 0xffff0000u);
+            }
+            a += __shfl_xor(a, 1);
+            a += __shfl_xor(a, 2);
+            a += __shfl_xor(a, 4);
+            sc[u] = i < n_keys ? a : -1e30f;
+            mb = fmaxf(mb, sc[u]);
+        }
+        mb = fmaxf(mb, __shfl_xor(mb, 8));
+        mb = fmaxf(mb, __shfl_xor(mb, 16));
+        mb = fmaxf(mb, __shfl_xor(mb, 32));
+        const float m_new = fmaxf(m_run, mb);
+        const float resc = __expf(m_run - m_new);  // 0 on the first block (m_run = -1e30), 1 when the max is unchanged
+        l_run *= resc;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oa[j] *= resc;
+#pragma unroll
+        for (int u = 0; u < SAT_U; ++u) {
+            const float pv = sc[u] > -1e29f ? __expf(sc[u] - m_new) : 0.f;
+            l_run += pv;  // the 8 lanes of a row hold the same pv: only the row groups are summed below
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                oa[2 * j] += pv * __uint_as_float(vv[u][j] << 16);
+                oa[2 * j + 1] += pv * __uint_as_float(vv[u][j] & 0xffff0000u);
+            }
+        }
+        m_run = m_new;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        oa[i] += __shfl_xor(oa[i], 8);
+        oa[i] += __shfl_xor(oa[i], 16);
+        oa[i] += __shfl_xor(oa[i], 32);
+    }
+    l_run += __shfl_xor(l_run, 8);
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+    if (rg == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wo_[wave][e8 * 8 + i] = oa[i];
+        if (e8 == 0) {
+            wm_[wave] = m_run;
+            wl_[wave] = l_run;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float M = wm_[0];
+#pragma unroll
+        for (int w = 1; w < SAT_NW; ++w) M = fmaxf(M, wm_[w]);
+        float o = 0.f, L = 0.f;
+#pragma unroll
+        for (int w = 0; w < SAT_NW; ++w) {
+            const float f = __expf(wm_[w] - M);  // a wave that saw no row has m = -1e30, l = 0, o = 0
+            o += wo_[w][tid] * f;
+            L += wl_[w] * f;
+        }
+        att[(long)b * d + h * 64 + tid] = f2bf(o / L);
+    }
+}
+
 // Combine flash-decoding partials -> bf16 head outputs.  grid B*H, 64 threads.
 __global__ __launch_bounds__(64) void dec_attn_combine_kernel(const float *__restrict__ part, int nsplit, int H,
                                                               int d, bf16_t *__restrict__ att) {
@@ -732,6 +848,9 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
         p.pf_tiles = a.pf_rows / 16;
         grid += p.pf_tiles;
     }
+    // two batch blocks share a weight tile through the L2 of ONE XCD only if blockIdx.x keeps its XCD (x % 8) in both
+    // rows of the grid: pad the row to a multiple of 8 (the extra workgroups take the warm-up exit and do nothing)
+    if (a.B > 16 && grid % 8 != 0) grid += 8 - grid % 8;
     const int key = a.a_mode * 8 + a.epi;
     switch (key) {
         case DA_LN * 8 + DE_QKV: {
@@ -819,6 +938,24 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
         dec_attn_combine_kernel<<<B * H, 64, 0, ctx->stream>>>(part, nsplit, H, H * 64, att);
         WM_HIP(hipGetLastError());
     }
+    return WM_OK;
+}
+
+int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H, int T_stride,
+                          int n_keys, const int *pos_ptr, bf16_t *att, const bf16_t *pf_ptr, int pf_rows, int pf_k) {
+    WM_REQUIRE(T_stride <= ATT_MAXK && n_keys <= ATT_MAXK && (pos_ptr || n_keys >= 1), WM_ERR_INVALID,
+               "dec_self_attention: 1..%d keys", ATT_MAXK);
+    WmProfScope ps(&ctx->prof, "dec_attn_self", ctx->stream);
+    static const bool no_pf = getenv("WM_NO_PREFETCH") != nullptr;
+    int gx = B * H;
+    long tile_bytes = 0;
+    if (!no_pf && pf_ptr && gx % 8 == 0 && pf_rows >= 16) {
+        tile_bytes = 16L * pf_k * 2;
+        gx += pf_rows / 16;
+    }
+    dec_self_attn_kernel<<<gx, SAT_NW * 64, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, B * H,
+                                                             (const char *)pf_ptr, tile_bytes);
+    WM_HIP(hipGetLastError());
     return WM_OK;
 }
 

@@ -498,7 +498,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.pos_ptr = m->dpos; a.n_ctx = T; a.n_head = H;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 2. causal self-attention over positions 0..pos
-        WM_TRY(wm_dec_attention(ctx, m->dq, kc, vc, B, H, T, 0, m->dpos, ns, m->dpart, m->datt, false, L.wo, d, d));
+        WM_TRY(wm_dec_self_attention(ctx, m->dq, kc, vc, B, H, T, 0, m->dpos, m->datt, L.wo, d, d));
         // 3. out-projection + residual
         memset(&a, 0, sizeof(a));
         a.a_mode = DA_BF16; a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wo; a.bias = L.bo;

@@ -221,6 +221,10 @@ int wm_dec_attn_splits(int B, int H);
 int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
                      int T_stride, int n_keys, const int *pos_ptr, int nsplit, float *part, bf16_t *att,
                      bool cross, const bf16_t *pf_ptr = nullptr, int pf_rows = 0, int pf_k = 0);
+// The decoder's causal self-attention (<= 448 cached rows per pair): one 4-wave workgroup per (sequence, head).
+int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H, int T_stride,
+                          int n_keys, const int *pos_ptr, bf16_t *att, const bf16_t *pf_ptr = nullptr, int pf_rows = 0,
+                          int pf_k = 0);
 // Close a decode step (one workgroup): reduce the per-tile packed maxima of a DE_LOGITS launch;
 // chosen token of row b -> seq[(*pos_ptr + 1) * B + b] when that position is >= n_prompt;
 // (token - arg_first) -> result[b]; embed the tokens of position *pos_ptr + 1 into x (+ LayerNorm

@@ -155,7 +155,10 @@ def test_decode_gemv(ctx, B, N, K, ln):
 
 @pytest.mark.parametrize("B,H,T,n_keys,nsplit", [(2, 2, 448, 1, 1), (2, 2, 448, 37, 1), (1, 3, 448, 448, 1),
                                                  (2, 2, 1500, 1500, 4), (1, 1, 1500, 1500, 3), (8, 20, 1500, 1500, 1),
-                                                 (3, 2, 448, 130, 8)])
+                                                 (3, 2, 448, 130, 8),
+                                                 # nsplit 0 = the decoder's self-attention kernel (4-wave workgroup per pair)
+                                                 (2, 2, 448, 1, 0), (2, 3, 448, 37, 0), (1, 3, 448, 128, 0),
+                                                 (3, 2, 448, 129, 0), (2, 2, 448, 448, 0), (32, 20, 448, 227, 0)])
 def test_decode_attention(ctx, B, H, T, n_keys, nsplit):
     rng = np.random.default_rng(T + n_keys)
     q = rng.standard_normal((B, H * 64)).astype(np.float32)
