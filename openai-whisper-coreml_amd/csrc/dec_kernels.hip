@@ -57,7 +57,7 @@ struct DecGemvDev {
     const float *x, *ln_g, *ln_b;
     const float *stats_in;  // DA_LN: [stats_parts][16][2] partial (sum x, sum x^2) per row
     int stats_parts;
-    long stats_stride;      // floats between the statistics of consecutive 16-row batch blocks (blockIdx.y)
+    long stats_stride;      // floats between the statistics of consecutive 16-row batch blocks
     float *stats_out;       // DE_RESID: this launch's per-tile partials of the UPDATED residual
     const bf16_t *a_bf16;
     float *out_f32;
@@ -67,7 +67,7 @@ struct DecGemvDev {
     int n_ctx, n_head;
     long ldo;
     unsigned long long *tilemax;  // [B][n_tiles] (DE_LOGITS)
-    int n_tiles;
+    int n_tiles, n_tiles_pad;  // n_tiles_pad: n_tiles rounded up to 8 when the batch has more than one 16-row block
     int arg_first, arg_last;
     const unsigned *mask;  // DE_LOGITS: suppressed-token bitmaps [2][mask_words] or null
     int mask_words, mask_first_pos;
@@ -109,23 +109,30 @@ constexpr int WG_MAX = 12;
 template <int AMODE, int EPI, int NW>
 __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x >= p.n_tiles) {  // workgroup-uniform
-        if (blockIdx.y == 0 && (int)blockIdx.x - p.n_tiles < p.pf_tiles)
-            l2_warm_tile(p.pf_ptr, p.pf_tile_bytes, (int)blockIdx.x - p.n_tiles, NW * 64);
+    // Batches above 16 run as nblk blocks of 16 rows (the MFMA's M) on the same weight tile.  Workgroup id ->
+    // (tile, block): ids 8g .. 8g+7 are tiles 8(g / nblk) .. +7 of block g % nblk, so the blocks of a tile are
+    // dispatched back to back AND on the same XCD (id % 8): the later blocks' weight reads hit the L2 the first one
+    // filled -- one HBM stream for all rows.  (nblk == 1: id == tile.)
+    const int nblk = (p.B + 15) >> 4;
+    const int wg = blockIdx.x;
+    const int grp = wg >> 3;
+    const int tile = (grp / nblk) * 8 + (wg & 7);
+    const int blk = grp % nblk;
+    if (wg >= p.n_tiles_pad * nblk || tile >= p.n_tiles) {  // workgroup-uniform: warm-up workgroups and row padding
+        const int t = wg - p.n_tiles_pad * nblk;
+        if (t >= 0 && t < p.pf_tiles) l2_warm_tile(p.pf_ptr, p.pf_tile_bytes, t, NW * 64);
         return;
     }
-    // Batches above 16 run as blockIdx.y blocks of 16 rows (the MFMA's M): same weight tile, so the second block's
-    // weight reads hit the L2 the first one filled (n_tiles % 8 == 0 puts both on one XCD) -- one HBM stream for all rows.
-    if (blockIdx.y != 0) {  // workgroup-uniform: rebase every per-row pointer of the by-value argument block
-        const long r0 = (long)blockIdx.y * 16;
+    if (blk != 0) {  // workgroup-uniform: rebase every per-row pointer of the by-value argument block
+        const long r0 = (long)blk * 16;
         if (p.x) p.x += r0 * p.K;
         if (p.a_bf16) p.a_bf16 += r0 * p.K;
         if (p.out_f32) p.out_f32 += r0 * (EPI == DE_QKV ? (long)(p.N / 3) : p.ldo);
         if (p.out_bf16) p.out_bf16 += r0 * p.ldo;
         if (p.kcache) p.kcache += r0 * p.n_head * p.n_ctx * 64;
         if (p.vcache) p.vcache += r0 * p.n_head * p.n_ctx * 64;
-        if (p.stats_in) p.stats_in += (long)blockIdx.y * p.stats_stride;
-        if (p.stats_out) p.stats_out += (long)blockIdx.y * p.stats_stride;
+        if (p.stats_in) p.stats_in += (long)blk * p.stats_stride;
+        if (p.stats_out) p.stats_out += (long)blk * p.stats_stride;
         if (p.tilemax) p.tilemax += r0 * p.n_tiles;
         p.B -= (int)r0;
     }
@@ -135,12 +142,12 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
     char *xs_all = (char *)(part + 2 * NW * 16);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrow = lane & 15, kq = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = tile * 16;
     const int kbase = wave * p.KC;
     const int nsteps = p.KC >> 5;
     // fragment-tiled weights (WL_TILED): k-step s of n-tile t is the contiguous KiB at
     // ((t * K/32 + s) * 64 + lane) * 8 -- one perfectly coalesced dwordx4 per lane per step
-    const bf16_t *wp = p.W + (((long)blockIdx.x * (p.K >> 5) + (long)wave * nsteps) * 64 + lane) * 8;
+    const bf16_t *wp = p.W + (((long)tile * (p.K >> 5) + (long)wave * nsteps) * 64 + lane) * 8;
     const bool live = nrow < p.B;
     const int rowc = live ? nrow : p.B - 1;  // clamped batch row for unconditional loads
     const int xs_stride = (p.KC + 8) * 2;    // bytes; the 16 B pad keeps ds_read_b128 conflict-free
@@ -203,13 +210,20 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
             gv[u] = *(const float4 *)(p.ln_g + kbase + 4 * j4c[u]);
             bv[u] = *(const float4 *)(p.ln_b + kbase + 4 * j4c[u]);
         }
-        float4 xv[8][2];
+        // activation rows travel in groups of four through two register buffers: rows 0-3 and 4-7 are requested
+        // here, each later group as soon as the buffer it reuses has been consumed (64 VGPRs at any batch size;
+        // holding all 16 rows cost 128 and a third of the resident workgroups)
+        float4 xa[4][2], xb[4][2];
+        auto fetch = [&](float4 (&xr)[4][2], int b0) {
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int bc = b < p.B ? b : p.B - 1;
+            for (int b = 0; b < 4; ++b) {
+                const int bc = b0 + b < p.B ? b0 + b : p.B - 1;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) xv[b][u] = *(const float4 *)(p.x + (long)bc * p.K + kbase + 4 * j4c[u]);
-        }
+                for (int u = 0; u < 2; ++u) xr[b][u] = *(const float4 *)(p.x + (long)bc * p.K + kbase + 4 * j4c[u]);
+            }
+        };
+        fetch(xa, 0);
+        fetch(xb, 4);
         {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -226,21 +240,10 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
             const float rstd = rsqrtf(var + 1e-5f);
             if (lane < 16) *(float2 *)(st + lane * 2) = make_float2(rstd, -mean * rstd);  // y = x*rstd - mean*rstd
         }
-        // rows 8..15 (B > 8, wave-uniform): requested as soon as the statistics registers are free, BEFORE the first
-        // eight rows are normalised, so the prologue still has a single activation round trip on its critical path
-        float4 xw[8][2];
-        if (p.B > 8) {
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int bc = 8 + b < p.B ? 8 + b : p.B - 1;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) xw[b][u] = *(const float4 *)(p.x + (long)bc * p.K + kbase + 4 * j4c[u]);
-            }
-        }
         // normalise: t = x*rstd + (-mean*rstd), y = t*g + b, as packed f32 FMAs; bf16 pairs by v_cvt_pk_bf16_f32
-        auto apply = [&](const float4 (&xr)[8][2], int b0) {
+        auto apply = [&](const float4 (&xr)[4][2], int b0) {
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
+            for (int b = 0; b < 4; ++b) {
                 const int br = b0 + b < p.B ? b0 + b : p.B - 1;  // duplicates rewrite row B-1 with equal data
                 const float2 ms = *(const float2 *)(st + br * 2);
                 const f32x2 a2 = {ms.x, ms.x}, c2 = {ms.y, ms.y};
@@ -258,8 +261,12 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
                 }
             }
         };
-        apply(xv, 0);
-        if (p.B > 8) apply(xw, 8);
+        apply(xa, 0);
+        if (p.B > 8) fetch(xa, 8);    // wave-uniform branches: scalar, no divergence around the loads
+        if (p.B > 4) apply(xb, 4);
+        if (p.B > 12) fetch(xb, 12);
+        if (p.B > 8) apply(xa, 8);
+        if (p.B > 12) apply(xb, 12);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
                 const unsigned long long ok = __shfl_xor(key, o);
                 key = ok > key ? ok : key;
             }
-            if (b < p.B && nrow == 0) p.tilemax[(long)b * p.n_tiles + blockIdx.x] = key;
+            if (b < p.B && nrow == 0) p.tilemax[(long)b * p.n_tiles + tile] = key;
             if (b < p.B && nvalid && p.out_f32) p.out_f32[(long)b * p.ldo + n] = v;
             continue;
         }
@@ -344,7 +351,7 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
                 s1 += __shfl_xor(s1, o);
                 s2 += __shfl_xor(s2, o);
             }
-            if (p.stats_out && nrow == 0) *(float2 *)(p.stats_out + ((long)blockIdx.x * 16 + b) * 2) = make_float2(s1, s2);
+            if (p.stats_out && nrow == 0) *(float2 *)(p.stats_out + ((long)tile * 16 + b) * 2) = make_float2(s1, s2);
             continue;
         }
         if (b >= p.B || !nvalid) continue;
@@ -786,11 +793,11 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(void *dst, int is_bf16,
 template <int AMODE, int EPI>
 int launch_gemv_b(wm_ctx *ctx, const DecGemvDev &p, int nw, int gx) {
     hipStream_t s = ctx->stream;
-    const int bb = p.B < 16 ? p.B : 16;  // rows per batch block; blocks of 16 rows are blockIdx.y
+    const int bb = p.B < 16 ? p.B : 16;  // rows per batch block (LDS is sized for one block)
     size_t lds = (size_t)nw * 1024 + 2 * nw * 16 * 4;
     if (AMODE == DA_LN) lds += (size_t)nw * bb * (p.KC + 8) * 2;
     lds = (lds + 15) & ~(size_t)15;
-    const dim3 grid(gx, (p.B + 15) / 16);
+    const int grid = gx;
     switch (nw) {
         case 1: dec_gemv_kernel<AMODE, EPI, 1><<<grid, 64, lds, s>>>(p); break;
         case 2: dec_gemv_kernel<AMODE, EPI, 2><<<grid, 128, lds, s>>>(p); break;
@@ -838,19 +845,18 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     p.kcache = a.kcache; p.vcache = a.vcache; p.pos_ptr = a.pos_ptr; p.n_ctx = a.n_ctx; p.n_head = a.n_head;
     p.ldo = a.ldo; p.tilemax = a.argmax; p.arg_first = a.arg_first; p.arg_last = a.arg_last;
     p.mask = a.mask; p.mask_words = a.mask_words; p.mask_first_pos = a.mask_first_pos;
-    int grid = (a.N + 15) / 16;
-    p.n_tiles = grid;
+    const int nblk = (a.B + 15) / 16;
+    p.n_tiles = (a.N + 15) / 16;
+    p.n_tiles_pad = nblk > 1 ? (p.n_tiles + 7) / 8 * 8 : p.n_tiles;  // (tile, block) decode in the kernel needs rows of 8
+    int grid = p.n_tiles_pad * nblk;
     static const bool no_pf = getenv("WM_NO_PREFETCH") != nullptr;
     p.pf_ptr = nullptr; p.pf_tile_bytes = 0; p.pf_tiles = 0;
-    if (!no_pf && a.pf_ptr && a.pf_rows >= 16 && grid % 8 == 0) {
+    if (!no_pf && a.pf_ptr && a.pf_rows >= 16 && p.n_tiles % 8 == 0) {
         p.pf_ptr = (const char *)a.pf_ptr;
         p.pf_tile_bytes = 16L * a.pf_k * 2;
         p.pf_tiles = a.pf_rows / 16;
         grid += p.pf_tiles;
     }
-    // two batch blocks share a weight tile through the L2 of ONE XCD only if blockIdx.x keeps its XCD (x % 8) in both
-    // rows of the grid: pad the row to a multiple of 8 (the extra workgroups take the warm-up exit and do nothing)
-    if (a.B > 16 && grid % 8 != 0) grid += 8 - grid % 8;
     const int key = a.a_mode * 8 + a.epi;
     switch (key) {
         case DA_LN * 8 + DE_QKV: {
