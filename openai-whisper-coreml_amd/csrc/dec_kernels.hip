@@ -818,20 +818,23 @@ int launch_gemv_b(wm_ctx *ctx, const DecGemvDev &p, int nw, int gx) {
 // MFMA k-steps, all issued up front); the LayerNorm prologue needs KC <= 512 and NW <= 4.
 static int g_nw_override = 0;
 void wm_dec_gemv_set_waves_override(int nw) { g_nw_override = nw; }
-static int pick_waves(int K, bool ln) {
+static int pick_waves(int K, bool ln, int B) {
     if (g_nw_override > 0 && K % (32 * g_nw_override) == 0 && (!ln || (g_nw_override <= 4 && K / g_nw_override <= 512)))
         return g_nw_override;
     const int maxw = ln ? 4 : 16;
     int best = 1;
     for (int nw = 1; nw <= maxw; nw <<= 1)
         if (K % (32 * nw) == 0 && K / nw >= 256) best = nw;
+    // 16-wave workgroups are one per CU: with more than one batch block the grid (tiles x blocks) no longer fits in a
+    // single round, 8 waves (two workgroups per CU) do (fc2 at B = 16 / 32 / 64: 11.8 / 11.6 / 20.7 -> 11.0 / 10.7 / 17.0 us)
+    if (best == 16 && B > 8) best = 8;
     return best;
 }
 
 int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     WM_REQUIRE(a.B >= 1 && a.B <= WM_DEC_MAXB, WM_ERR_INVALID, "dec_gemv: B=%d out of range", a.B);
     WM_REQUIRE(a.K % 32 == 0, WM_ERR_INVALID, "dec_gemv: K=%d must be a multiple of 32", a.K);
-    const int nw = pick_waves(a.K, a.a_mode == DA_LN);
+    const int nw = pick_waves(a.K, a.a_mode == DA_LN, a.B);
     WM_REQUIRE(a.K % (32 * nw) == 0 && (a.a_mode != DA_LN || a.K / nw <= 512), WM_ERR_INVALID,
                "dec_gemv: K=%d cannot be split over %d waves", a.K, nw);
     WM_REQUIRE(a.a_mode != DA_LN || (a.stats_in && a.stats_parts >= 1 && a.stats_parts <= 80), WM_ERR_INVALID,
