@@ -556,111 +556,122 @@ __global__ __launch_bounds__(1024) void dec_attn_kernel(const float *__restrict_
 // walk the rows in blocks of 128 (4 waves x 8 rows x 4 loads; K and V of a block requested together), each wave
 // keeps its own running (max, sum, o[64]) -- no workgroup barrier inside the loop -- and the four partial results
 // are merged once through LDS.  fp32 softmax, bf16 head output, same row -> lane mapping as dec_attn_kernel.
-constexpr int SAT_NW = 4, SAT_U = 4;
-__global__ __launch_bounds__(SAT_NW * 64) void dec_self_attn_kernel(const float *__restrict__ q,
-                                                                    const bf16_t *__restrict__ kc,
-                                                                    const bf16_t *__restrict__ vc, int H, int d,
-                                                                    int T_stride, int n_keys_const,
-                                                                    const int *__restrict__ pos_ptr,
-                                                                    bf16_t *__restrict__ att, int n_bh,
-                                                                    const char *pf_ptr, long pf_tile_bytes) {
-    if ((int)blockIdx.x >= n_bh) {  // L2 warm-up workgroup for the next GEMV's weights
-        l2_warm_tile(pf_ptr, pf_tile_bytes, (int)blockIdx.x - n_bh, SAT_NW * 64);
+// The same kernel with 8 waves x 6 loads (blocks of 384 rows) is the cross-attention when several decode groups are
+// in flight: ~90 VGPRs let two workgroups share a CU, so one streams while the other reduces; n_wg <= n_bh workgroups
+// walk the pairs.  NT: non-temporal loads (a cache row is read once per step).
+template <int NW, int U, bool NT>
+__global__ __launch_bounds__(NW * 64) void dec_rows_attn_kernel(const float *__restrict__ q,
+                                                                const bf16_t *__restrict__ kc,
+                                                                const bf16_t *__restrict__ vc, int H, int d,
+                                                                int T_stride, int n_keys_const,
+                                                                const int *__restrict__ pos_ptr,
+                                                                bf16_t *__restrict__ att, int n_bh, int n_wg,
+                                                                const char *pf_ptr, long pf_tile_bytes) {
+    if ((int)blockIdx.x >= n_wg) {  // L2 warm-up workgroup for the next GEMV's weights
+        l2_warm_tile(pf_ptr, pf_tile_bytes, (int)blockIdx.x - n_wg, NW * 64);
         return;
     }
-    __shared__ float wm_[SAT_NW], wl_[SAT_NW];
-    __shared__ float wo_[SAT_NW][64];
-    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    __shared__ float wm_[NW], wl_[NW];
+    __shared__ float wo_[NW][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rg = lane >> 3, e8 = lane & 7;
     const int n_keys = pos_ptr ? (*pos_ptr + 1) : n_keys_const;
     const int last = n_keys - 1;
-    const bf16_t *kb = kc + (long)bh * T_stride * 64 + e8 * 8;
-    const bf16_t *vb = vc + (long)bh * T_stride * 64 + e8 * 8;
-    float qe[8];
-    {
-        const float *qp = q + (long)b * d + h * 64 + e8 * 8;
+    for (int bh = blockIdx.x; bh < n_bh; bh += n_wg) {
+        if (bh != (int)blockIdx.x) __syncthreads();  // the previous pair's merge has been read
+        const int b = bh / H, h = bh % H;
+        const bf16_t *kb = kc + (long)bh * T_stride * 64 + e8 * 8;
+        const bf16_t *vb = vc + (long)bh * T_stride * 64 + e8 * 8;
+        float qe[8];
+        {
+            const float *qp = q + (long)b * d + h * 64 + e8 * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) qe[i] = qp[i] * 0.125f;  // hd^-0.5
-    }
-    float m_run = -1e30f, l_run = 0.f;
-    float oa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int r0 = 0; r0 < n_keys; r0 += SAT_NW * 8 * SAT_U) {  // workgroup-uniform trip count
-        u32x4 kv[SAT_U], vv[SAT_U];
-#pragma unroll
-        for (int u = 0; u < SAT_U; ++u) {
-            int i = r0 + u * (SAT_NW * 8) + wave * 8 + rg;
-            i = i < n_keys ? i : last;  // clamped: unconditional loads
-            kv[u] = *(const u32x4 *)(kb + (long)i * 64);
-            vv[u] = *(const u32x4 *)(vb + (long)i * 64);
+            for (int i = 0; i < 8; ++i) qe[i] = qp[i] * 0.125f;  // hd^-0.5
         }
-        float sc[SAT_U];
-        float mb = -1e30f;
+        float m_run = -1e30f, l_run = 0.f;
+        float oa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int r0 = 0; r0 < n_keys; r0 += NW * 8 * U) {  // workgroup-uniform trip count
+            u32x4 kv[U], vv[U];
 #pragma unroll
-        for (int u = 0; u < SAT_U; ++u) {
-            const int i = r0 + u * (SAT_NW * 8) + wave * 8 + rg;
-            float a = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                a += qe[2 * j] * __uint_as_float(kv[u][j] << 16);
-                a += qe[2 * j + 1] * __uint_as_float(kv[u][j] & 0xffff0000u);
+            for (int u = 0; u < U; ++u) {
+                int i = r0 + u * (NW * 8) + wave * 8 + rg;
+                i = i < n_keys ? i : last;  // clamped: unconditional loads
+                if (NT) {
+                    kv[u] = __builtin_nontemporal_load((const u32x4 *)(kb + (long)i * 64));
+                    vv[u] = __builtin_nontemporal_load((const u32x4 *)(vb + (long)i * 64));
+                } else {
+                    kv[u] = *(const u32x4 *)(kb + (long)i * 64);
+                    vv[u] = *(const u32x4 *)(vb + (long)i * 64);
+                }
             }
-            a += __shfl_xor(a, 1);
-            a += __shfl_xor(a, 2);
-            a += __shfl_xor(a, 4);
-            sc[u] = i < n_keys ? a : -1e30f;
-            mb = fmaxf(mb, sc[u]);
+            float sc[U];
+            float mb = -1e30f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = r0 + u * (NW * 8) + wave * 8 + rg;
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a += qe[2 * j] * __uint_as_float(kv[u][j] << 16);
+                    a += qe[2 * j + 1] * __uint_as_float(kv[u][j] & 0xffff0000u);
+                }
+                a += __shfl_xor(a, 1);
+                a += __shfl_xor(a, 2);
+                a += __shfl_xor(a, 4);
+                sc[u] = i < n_keys ? a : -1e30f;
+                mb = fmaxf(mb, sc[u]);
+            }
+            mb = fmaxf(mb, __shfl_xor(mb, 8));
+            mb = fmaxf(mb, __shfl_xor(mb, 16));
+            mb = fmaxf(mb, __shfl_xor(mb, 32));
+            const float m_new = fmaxf(m_run, mb);
+            const float resc = __expf(m_run - m_new);  // 0 on the first block (m_run = -1e30), 1 when the max is unchanged
+            l_run *= resc;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) oa[j] *= resc;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float pv = sc[u] > -1e29f ? __expf(sc[u] - m_new) : 0.f;
+                l_run += pv;  // the 8 lanes of a row hold the same pv: only the row groups are summed below
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    oa[2 * j] += pv * __uint_as_float(vv[u][j] << 16);
+                    oa[2 * j + 1] += pv * __uint_as_float(vv[u][j] & 0xffff0000u);
+                }
+            }
+            m_run = m_new;
         }
-        mb = fmaxf(mb, __shfl_xor(mb, 8));
-        mb = fmaxf(mb, __shfl_xor(mb, 16));
-        mb = fmaxf(mb, __shfl_xor(mb, 32));
-        const float m_new = fmaxf(m_run, mb);
-        const float resc = __expf(m_run - m_new);  // 0 on the first block (m_run = -1e30), 1 when the max is unchanged
-        l_run *= resc;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) oa[j] *= resc;
+        for (int i = 0; i < 8; ++i) {
+            oa[i] += __shfl_xor(oa[i], 8);
+            oa[i] += __shfl_xor(oa[i], 16);
+            oa[i] += __shfl_xor(oa[i], 32);
+        }
+        l_run += __shfl_xor(l_run, 8);
+        l_run += __shfl_xor(l_run, 16);
+        l_run += __shfl_xor(l_run, 32);
+        if (rg == 0) {
 #pragma unroll
-        for (int u = 0; u < SAT_U; ++u) {
-            const float pv = sc[u] > -1e29f ? __expf(sc[u] - m_new) : 0.f;
-            l_run += pv;  // the 8 lanes of a row hold the same pv: only the row groups are summed below
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                oa[2 * j] += pv * __uint_as_float(vv[u][j] << 16);
-                oa[2 * j + 1] += pv * __uint_as_float(vv[u][j] & 0xffff0000u);
+            for (int i = 0; i < 8; ++i) wo_[wave][e8 * 8 + i] = oa[i];
+            if (e8 == 0) {
+                wm_[wave] = m_run;
+                wl_[wave] = l_run;
             }
         }
-        m_run = m_new;
-    }
+        __syncthreads();
+        if (tid < 64) {
+            float M = wm_[0];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        oa[i] += __shfl_xor(oa[i], 8);
-        oa[i] += __shfl_xor(oa[i], 16);
-        oa[i] += __shfl_xor(oa[i], 32);
-    }
-    l_run += __shfl_xor(l_run, 8);
-    l_run += __shfl_xor(l_run, 16);
-    l_run += __shfl_xor(l_run, 32);
-    if (rg == 0) {
+            for (int w = 1; w < NW; ++w) M = fmaxf(M, wm_[w]);
+            float o = 0.f, L = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) wo_[wave][e8 * 8 + i] = oa[i];
-        if (e8 == 0) {
-            wm_[wave] = m_run;
-            wl_[wave] = l_run;
+            for (int w = 0; w < NW; ++w) {
+                const float f = __expf(wm_[w] - M);  // a wave that saw no row has m = -1e30, l = 0, o = 0
+                o += wo_[w][tid] * f;
+                L += wl_[w] * f;
+            }
+            att[(long)b * d + h * 64 + tid] = f2bf(o / L);
         }
-    }
-    __syncthreads();
-    if (tid < 64) {
-        float M = wm_[0];
-#pragma unroll
-        for (int w = 1; w < SAT_NW; ++w) M = fmaxf(M, wm_[w]);
-        float o = 0.f, L = 0.f;
-#pragma unroll
-        for (int w = 0; w < SAT_NW; ++w) {
-            const float f = __expf(wm_[w] - M);  // a wave that saw no row has m = -1e30, l = 0, o = 0
-            o += wo_[w][tid] * f;
-            L += wl_[w] * f;
-        }
-        att[(long)b * d + h * 64 + tid] = f2bf(o / L);
     }
 }
 
@@ -916,6 +927,31 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
     {
         WmProfScope ps(&ctx->prof, cross ? "dec_attn_cross" : "dec_attn_self", ctx->stream);
         static const bool no_pf = getenv("WM_NO_PREFETCH") != nullptr;
+        // Cross-attention over the full cache (nsplit == 1): the block-streaming kernel with 8 waves x 4 loads --
+        // ~90 VGPRs, so two workgroups (or a GEMV of another decode group) share a CU -- and at most 256 workgroups
+        // walking the pairs.  Measured alone at B = 8 / 32 / 64: 12.5-13.8 / 41 / 75 us (4.6-4.9 / 6.0 / 6.5 TB/s) against
+        // 14.2 / 47 / 92 us for the 16-wave kernel below; under three-way concurrency both saturate at 6.7-7.0 TB/s.
+        // WM_XATTN_ROWS=0 selects the 16-wave kernel, WM_XATTN_WGS the workgroup cap (A/B probes).
+        static const int rows_mode = getenv("WM_XATTN_ROWS") ? atoi(getenv("WM_XATTN_ROWS")) : 1;
+        if (cross && nsplit == 1 && rows_mode > 0 && !pos_ptr) {
+            static const int env_cap2 = getenv("WM_XATTN_WGS") ? atoi(getenv("WM_XATTN_WGS")) : 0;
+            const int cap2 = env_cap2 > 0 ? env_cap2 : 256;
+            int n_wg = B * H;
+            if (n_wg > cap2) {
+                const int rounds = (n_wg + cap2 - 1) / cap2;
+                n_wg = (n_wg + rounds - 1) / rounds;  // balanced: every workgroup walks `rounds` (or rounds - 1) pairs
+            }
+            int gx = n_wg;
+            long tile_bytes = 0;
+            if (!no_pf && pf_ptr && gx % 8 == 0 && pf_rows >= 16) {
+                tile_bytes = 16L * pf_k * 2;
+                gx += pf_rows / 16;
+            }
+            dec_rows_attn_kernel<8, 4, true><<<gx, 512, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, nullptr, att,
+                                                                         B * H, n_wg, (const char *)pf_ptr, tile_bytes);
+            WM_HIP(hipGetLastError());
+            return WM_OK;
+        }
         // Compute workgroups: one per (sequence, head) up to a cap (default 160 = what B = 8 x 20 heads uses; measured:
         // more than that blocks the CUs the other decode groups need).  WM_XATTN_WGS overrides (A/B probes).
         static const int env_cap = getenv("WM_XATTN_WGS") ? atoi(getenv("WM_XATTN_WGS")) : 0;
@@ -962,8 +998,8 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
         tile_bytes = 16L * pf_k * 2;
         gx += pf_rows / 16;
     }
-    dec_self_attn_kernel<<<gx, SAT_NW * 64, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, B * H,
-                                                             (const char *)pf_ptr, tile_bytes);
+    dec_rows_attn_kernel<4, 4, false><<<gx, 256, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att,
+                                                                  B * H, B * H, (const char *)pf_ptr, tile_bytes);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

@@ -597,11 +597,12 @@ extern "C" int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, 
     WM_TRY(up(&dp, nullptr, (size_t)B * H * (nsplit > 0 ? nsplit : 1) * 66 * 4, s));
     void *datt;
     WM_TRY(up(&datt, nullptr, (size_t)B * H * 64 * 2, s));
-    // nsplit == 0 selects the decoder's self-attention kernel (one 4-wave workgroup per pair)
+    // nsplit == 0 selects the decoder's self-attention kernel (one 4-wave workgroup per pair), nsplit == -1 the
+    // cross-attention launch path (8-wave block-streaming kernel, capped grid)
     int rc = nsplit == 0 ? wm_dec_self_attention(ctx, (const float *)dq, (const bf16_t *)dk, (const bf16_t *)dv, B, H, T,
                                                  n_keys, nullptr, (bf16_t *)datt)
                          : wm_dec_attention(ctx, (const float *)dq, (const bf16_t *)dk, (const bf16_t *)dv, B, H, T, n_keys,
-                                            nullptr, nsplit, (float *)dp, (bf16_t *)datt, false);
+                                            nullptr, nsplit < 0 ? 1 : nsplit, (float *)dp, (bf16_t *)datt, nsplit < 0);
     if (rc == WM_OK) {
         std::vector<bf16_t> o16((size_t)B * H * 64);
         WM_HIP(hipMemcpyAsync(o16.data(), datt, o16.size() * 2, hipMemcpyDeviceToHost, s));

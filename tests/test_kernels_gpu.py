@@ -158,7 +158,10 @@ def test_decode_gemv(ctx, B, N, K, ln):
                                                  (3, 2, 448, 130, 8),
                                                  # nsplit 0 = the decoder's self-attention kernel (4-wave workgroup per pair)
                                                  (2, 2, 448, 1, 0), (2, 3, 448, 37, 0), (1, 3, 448, 128, 0),
-                                                 (3, 2, 448, 129, 0), (2, 2, 448, 448, 0), (32, 20, 448, 227, 0)])
+                                                 (3, 2, 448, 129, 0), (2, 2, 448, 448, 0), (32, 20, 448, 227, 0),
+                                                 # nsplit -1 = the cross-attention path (8-wave block-streaming kernel, <= 256 workgroups)
+                                                 (8, 20, 1500, 1500, -1), (3, 2, 1500, 1500, -1), (40, 20, 1500, 1500, -1),
+                                                 (2, 2, 1500, 300, -1)])
 def test_decode_attention(ctx, B, H, T, n_keys, nsplit):
     rng = np.random.default_rng(T + n_keys)
     q = rng.standard_normal((B, H * 64)).astype(np.float32)
