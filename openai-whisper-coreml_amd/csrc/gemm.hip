@@ -158,6 +158,63 @@ __device__ __forceinline__ void store_tile(const GemmDev &p, const f32x4 (&acc)[
     }
 }
 
+// LDS-staged epilogue for the bf16-output epilogues: each wave transposes its fragments through a private LDS region
+// (64 rows x 64 columns per pass, 144-byte row stride) so that the global stores are 16 bytes per lane, 8 lanes = one
+// 128-byte line of a C row -- 16 store instructions per lane for a 128 x 64 sub-tile instead of 128 two-byte ones.
+// Wave-local: no workgroup barrier (the caller guarantees every wave is done reading the main loop's LDS image).
+// Requires N % 64 == 0 (a wave's 64 columns are entirely inside C and, for EPI_QKV_ENC / EPI_XKV, inside one head).
+constexpr int STAGE_ROW_BYTES = 144;
+constexpr int STAGE_WAVE_BYTES = 64 * STAGE_ROW_BYTES;  // 9216 B per wave
+
+template <int EPI, int MI, int NJ>
+__device__ __forceinline__ void store_tile_staged(const GemmDev &p, const f32x4 (&acc)[MI][NJ], int mwave0, int nwave0,
+                                                  char *L, int lane) {
+    static_assert(NJ == 4 && MI % 4 == 0, "a wave sub-tile is (MI x 16) x 64");
+    static_assert(EPI == EPI_BIAS_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV_ENC || EPI == EPI_XKV, "bf16 outputs");
+    if (nwave0 >= p.N) return;  // wave-uniform
+    const int frow = lane & 15, fq = lane >> 4;
+    float bv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bv[j] = p.bias ? p.bias[nwave0 + j * 16 + frow] : 0.f;
+    // wave-uniform column part of the destination
+    long coff = nwave0;
+    if (EPI == EPI_XKV) {  // the wave's 64 columns are one (kv, head): out[kv][b][h][s][64]
+        const int kv = nwave0 / p.d_model, h = (nwave0 - kv * p.d_model) >> 6;
+        coff = ((long)(kv * p.batch) * p.n_head + h) * p.seq * 64;
+    }
+    const unsigned rpb = (unsigned)p.c_rpb, seq = (unsigned)(p.seq > 0 ? p.seq : 1);
+    const int rrow = lane >> 3, chunk = lane & 7;
+#pragma unroll
+    for (int ps = 0; ps < MI / 4; ++ps) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[ps * 4 + ii][j][r] + bv[j];
+                    if (EPI == EPI_GELU_BF16) v = gelu_erf(v);
+                    *(bf16_t *)(L + (ii * 16 + fq * 4 + r) * STAGE_ROW_BYTES + (j * 16 + frow) * 2) = f2bf(v);
+                }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = t * 8 + rrow;
+            const uint4 val = *(const uint4 *)(L + row * STAGE_ROW_BYTES + chunk * 16);
+            const unsigned m = (unsigned)(mwave0 + ps * 64 + row);
+            if ((int)m >= p.M) continue;
+            long roff;
+            if (EPI == EPI_XKV) {
+                const unsigned b = m / seq, sq = m - b * seq;
+                roff = ((long)b * p.n_head * p.seq + sq) * 64;
+            } else {
+                const unsigned q = m / rpb, rem = m - q * rpb;
+                roff = (long)q * p.c_bstride + (long)rem * p.c_rstride;
+            }
+            *(uint4 *)((bf16_t *)p.C + roff + coff + chunk * 8) = val;
+        }
+    }
+}
+
 // XCD-aware, bijective workgroup -> tile map: the 8 XCDs (private L2s) each get a contiguous range of tiles,
 // walked in GM x tiles_n groups so that the tiles an XCD runs concurrently share A and W panels in its L2.
 __device__ __forceinline__ void tile_of_workgroup(const GemmDev &p, int &tm, int &tn) {
@@ -255,6 +312,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
     }
 
     // ---- epilogue: D fragment (i,j): col n = lane & 15, rows m = (lane >> 4) * 4 + r ------
+    if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV_ENC || EPI == EPI_XKV) {
+        // bf16 outputs leave through LDS (the loop's last __syncthreads() means nobody reads the operand tiles any more);
+        // the V^T third of the QKV projection keeps its transposed register path
+        const int nwave0 = n0 + wc * 64;
+        if (p.N % 64 == 0 && !(EPI == EPI_QKV_ENC && nwave0 >= 2 * p.d_model)) {  // wave-uniform
+            store_tile_staged<EPI, 4, 4>(p, acc, m0 + wr * 64, nwave0, &lds[0][0][0] + wave * STAGE_WAVE_BYTES, lane);
+            return;
+        }
+    }
     store_tile<EPI, 4, 4>(p, acc, m0 + wr * 64 + fq * 4, n0 + wc * 64 + frow);
 }
 
@@ -429,6 +495,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
     WM_PHASE(3, false, 0, t);
     if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with row 1's last barrier
 
+    if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV_ENC || EPI == EPI_XKV) {
+        // bf16 outputs leave through LDS: after the barrier above every wave has finished reading the operand tiles
+        const int nwave0 = n0 + wc * 64;
+        if (p.N % 64 == 0 && !(EPI == EPI_QKV_ENC && nwave0 >= 2 * p.d_model)) {  // wave-uniform
+            store_tile_staged<EPI, 8, 4>(p, acc, m0 + wr * 128, nwave0, lds + wave * STAGE_WAVE_BYTES, lane);
+            return;
+        }
+    }
     store_tile<EPI, 8, 4>(p, acc, m0 + wr * 128 + fq * 4, n0 + wc * 64 + frow);
 #undef WM_PHASE
 #undef WM_MFMA_QUAD
