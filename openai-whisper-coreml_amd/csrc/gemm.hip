@@ -215,6 +215,47 @@ __device__ __forceinline__ void store_tile_staged(const GemmDev &p, const f32x4 
     }
 }
 
+// The same for the f32 residual update C += A.W^T + bias: 32 rows x 64 columns per pass (272-byte row stride), then
+// every lane reads 4 consecutive floats, adds them to 16 bytes of C and writes them back: 32 read-modify-writes of
+// 16 bytes per lane for a 128 x 64 sub-tile instead of 128 of 4 bytes.
+constexpr int STAGE_F32_ROW_BYTES = 272;
+
+template <int MI, int NJ>
+__device__ __forceinline__ void resid_tile_staged(const GemmDev &p, const f32x4 (&acc)[MI][NJ], int mwave0, int nwave0,
+                                                  char *L, int lane) {
+    static_assert(NJ == 4 && MI % 2 == 0, "a wave sub-tile is (MI x 16) x 64");
+    if (nwave0 >= p.N) return;  // wave-uniform
+    const int frow = lane & 15, fq = lane >> 4;
+    float bv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bv[j] = p.bias ? p.bias[nwave0 + j * 16 + frow] : 0.f;
+    const unsigned rpb = (unsigned)p.c_rpb;
+    const int rrow = lane >> 4, c4 = lane & 15;
+#pragma unroll
+    for (int ps = 0; ps < MI / 2; ++ps) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *(float *)(L + (ii * 16 + fq * 4 + r) * STAGE_F32_ROW_BYTES + (j * 16 + frow) * 4) =
+                        acc[ps * 2 + ii][j][r] + bv[j];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = t * 4 + rrow;
+            const float4 v = *(const float4 *)(L + row * STAGE_F32_ROW_BYTES + c4 * 16);
+            const unsigned m = (unsigned)(mwave0 + ps * 32 + row);
+            if ((int)m >= p.M) continue;
+            const unsigned q = m / rpb, rem = m - q * rpb;
+            float4 *dst = (float4 *)((float *)p.C + (long)q * p.c_bstride + (long)rem * p.c_rstride + nwave0 + c4 * 4);
+            float4 c = *dst;
+            c.x += v.x; c.y += v.y; c.z += v.z; c.w += v.w;
+            *dst = c;
+        }
+    }
+}
+
 // XCD-aware, bijective workgroup -> tile map: the 8 XCDs (private L2s) each get a contiguous range of tiles,
 // walked in GM x tiles_n groups so that the tiles an XCD runs concurrently share A and W panels in its L2.
 __device__ __forceinline__ void tile_of_workgroup(const GemmDev &p, int &tm, int &tn) {
@@ -318,6 +359,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
         const int nwave0 = n0 + wc * 64;
         if (p.N % 64 == 0 && !(EPI == EPI_QKV_ENC && nwave0 >= 2 * p.d_model)) {  // wave-uniform
             store_tile_staged<EPI, 4, 4>(p, acc, m0 + wr * 64, nwave0, &lds[0][0][0] + wave * STAGE_WAVE_BYTES, lane);
+            return;
+        }
+    }
+    if constexpr (EPI == EPI_RESID_F32) {
+        if (p.N % 64 == 0) {
+            resid_tile_staged<4, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, &lds[0][0][0] + wave * STAGE_WAVE_BYTES, lane);
             return;
         }
     }
@@ -500,6 +547,12 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
         const int nwave0 = n0 + wc * 64;
         if (p.N % 64 == 0 && !(EPI == EPI_QKV_ENC && nwave0 >= 2 * p.d_model)) {  // wave-uniform
             store_tile_staged<EPI, 8, 4>(p, acc, m0 + wr * 128, nwave0, lds + wave * STAGE_WAVE_BYTES, lane);
+            return;
+        }
+    }
+    if constexpr (EPI == EPI_RESID_F32) {
+        if (p.N % 64 == 0) {
+            resid_tile_staged<8, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, lds + wave * STAGE_WAVE_BYTES, lane);
             return;
         }
     }
