@@ -7,6 +7,7 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
 
 __device__ __forceinline__ bf16_t f2bf(float f) {
     unsigned u = __float_as_uint(f);
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restric
 constexpr int KS_STRIDE = 144;  // bytes per K row in LDS (128 + 16 pad): conflict-free b128
 constexpr int VS_STRIDE = 136;  // bytes per V^T row in LDS (128 + 8 pad): conflict-free b64
 
-__global__ __launch_bounds__(256, 1) void enc_attn_kernel(const bf16_t *__restrict__ qk,
+__global__ __launch_bounds__(256, 4) void enc_attn_kernel(const bf16_t *__restrict__ qk,
                                                           const bf16_t *__restrict__ vt,
                                                           bf16_t *__restrict__ att, int H, int S,
                                                           int S_pad, int d) {
@@ -201,31 +202,35 @@ __global__ __launch_bounds__(256, 1) void enc_attn_kernel(const bf16_t *__restri
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
         const float m_new = fmaxf(m_run, mloc);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        const float mc = -m_new * c;
         float lsum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f((st[kb][r] - m_new) * c);
+                const float pv = __builtin_amdgcn_exp2f(fmaf(st[kb][r], c, mc));  // one FMA per score, not sub + mul
                 st[kb][r] = pv;
                 lsum += pv;
             }
         lsum += __shfl_xor(lsum, 32);
         l_run = l_run * alpha + lsum;
         m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {  // wave-uniform: the running maxima settle after a few tiles
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            oacc[0][r] *= alpha;
-            oacc[1][r] *= alpha;
+            for (int r = 0; r < 16; ++r) {
+                oacc[0][r] *= alpha;
+                oacc[1][r] *= alpha;
+            }
         }
         // ---- O^T += V^T P^T --------------------------------------------------------------
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int j2 = 0; j2 < 2; ++j2) {
-                bf16x8 pf;
+                f32x8 p8;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) pf[i] = (__bf16)st[kb][8 * j2 + i];
+                for (int i = 0; i < 8; ++i) p8[i] = st[kb][8 * j2 + i];
+                const bf16x8 pf = __builtin_convertvector(p8, bf16x8);  // 4 x v_cvt_pk_bf16_f32
                 const int kvoff = kb * 32 + 16 * j2 + 4 * hf;  // + {0..3} and + 8 + {0..3}
 #pragma unroll
                 for (int eb = 0; eb < 2; ++eb) {
