@@ -341,6 +341,17 @@ def test_large_v3_front_end_and_vocabulary(pkg):
         _check_choice(conf[b], int(got[b]))
     toks, _ = ctx.transcribe_greedy(pcm, [50258, 50259, 50360, 50364], 3)
     assert toks.shape == (2, 3) and toks.max() < 51866
+    # decoder at the real width (d = 1280, 20 heads, K = 5120 MLP, 51 866-row tied embedding): teacher-forced logits
+    tok = np.array([[50258, 50259, 50360], [50258, 50300, 50364]], dtype=np.int32)
+    got_l = ctx.decode_logits(tok, want)
+    ref_l = R.decode_logits(sd, dims, tok, want).numpy()
+    e = R.rel_l2(got_l, ref_l)
+    print("large-v3 (2 layers) logits rel-L2", e)
+    assert e <= LOGIT_TOL
+    # ... and a decode group of 20 sequences (two batch blocks at this width) equals the same chunks alone
+    idx = [0, 1] * 10
+    many, _ = ctx.transcribe_greedy(pcm[idx], [50258, 50259, 50360, 50364], 3)
+    assert np.array_equal(many, toks[idx])
     ctx.close()
 
 
