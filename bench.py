@@ -6,7 +6,7 @@ One "step" = one pass of the hot path over one batch of synthetic 16 kHz audio t
 already resident in HBM (int16 PCM): log-mel front end -> encoder -> cross-attention K/V
 -> KV-cached greedy decode of 224 tokens (n_text_ctx // 2, EOT suppressed so the work is
 fixed) -> tokens on the host.  Steps are independent batches; the engine batches them continuously:
---fuse F (default 8) consecutive batches are decoded as ONE group of F*8 = 64 chunks (the decoder weights are
+--fuse F (default 12) consecutive batches are decoded as ONE group of F*8 = 96 chunks (the decoder weights are
 streamed once per group and position), and --inflight S (default 3) groups are kept in flight per GPU on S
 weight-sharing contexts (the decode chain of one group is latency-bound).  The latency of a single batch of 8
 is reported next to the pipelined throughput.  Everything runs through the C ABI of libwhisper_mi355x.so
@@ -146,15 +146,15 @@ def cpu_baseline(ctx, dims, pcm16_chunk, prompt):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=72)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large-v2")
     ap.add_argument("--batch", type=int, default=8, help="30 s chunks per GPU per step")
     ap.add_argument("--new-tokens", type=int, default=224)
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent batches kept in flight per GPU (each on its own HIP stream / context clone)")
-    ap.add_argument("--fuse", type=int, default=8,
-                    help="consecutive steps (batches) decoded together as ONE group of fuse*batch chunks (<= 64): the "
+    ap.add_argument("--fuse", type=int, default=12,
+                    help="consecutive steps (batches) decoded together as ONE group of fuse*batch chunks (<= 128): the "
                          "decoder weights are streamed once per group and position")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -183,7 +183,9 @@ def main():
     ctx.finalize()
 
     nb = args.batch
-    F = max(1, min(args.fuse, 64 // nb if nb <= 64 else 1))
+    F = max(1, min(args.fuse, 128 // nb if nb <= 128 else 1))
+    S = max(1, args.inflight)
+    F = min(F, max(1, -(-args.steps // S)))   # few timed steps: smaller groups rather than idle lanes
     chunks = [structured_pcm16() if i == 0 else synth_pcm16(rank * nb * F + i) for i in range(nb * F)]
     pcm = np.stack(chunks)
     d_pcm = ctx.to_device(pcm)
@@ -196,7 +198,6 @@ def main():
     # pipelined over S contexts that share the weights and own a HIP stream + KV caches each.
     import queue
     import threading
-    S = max(1, args.inflight)
     ctxs = [ctx] + [ctx.clone() for _ in range(S - 1)]
     gathered = None
 
@@ -248,7 +249,7 @@ def main():
         for c in ctxs:
             c.sync()
 
-    run_steps(max(args.warmup, 1) * S * F if args.warmup > 0 else 0)   # every context warmed (graph captured)
+    run_steps(max(args.warmup, S * F) if args.warmup > 0 else 0)   # >= one full round: every context warmed (graph captured)
     sync_all()
     t0 = time.perf_counter()
     stage = run_steps(args.steps)

@@ -137,7 +137,7 @@ int wm_detect_language(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t
 
 /* New surface asked for by BASELINE.json (not in the reference): front end + encoder +
  * KV-cached greedy decode of B independent 30 s chunks.  Any B >= 1: the call is cut into balanced
- * decode groups (8 .. 64 chunks) that run concurrently on up to $WM_LANES (default 3) weight-sharing
+ * decode groups (8 .. 128 chunks) that run concurrently on up to $WM_LANES (default 3) weight-sharing
  * lanes inside the context; tokens do not depend on the grouping (bit-level batch invariance).
  *   pcm        : [B][480000], dtype WM_I16 / WM_F32 / WM_F64, mem-space selectable;
  *   prompt     : i32 [n_prompt] initial tokens (e.g. {sot, lang, transcribe, notimestamps});

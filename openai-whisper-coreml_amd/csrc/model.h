@@ -178,7 +178,7 @@ int wm_enc_attention(wm_ctx *ctx, const bf16_t *qk, const bf16_t *vt, bf16_t *at
                      int S, int S_pad, int d);
 
 // dec_kernels.hip
-constexpr int WM_DEC_MAXB = 64;  // decode group: up to four batch blocks of 16 rows (the MFMA M dimension)
+constexpr int WM_DEC_MAXB = 128;  // decode group: up to eight batch blocks of 16 rows (the MFMA M dimension)
 constexpr int WM_MAXSPLIT = 8;  // flash-decoding splits of single-query attention (small batches)
 enum DecAMode { DA_LN = 0, DA_BF16 = 1 };
 enum DecEpi { DE_QKV = 0, DE_Q = 1, DE_RESID = 2, DE_GELU = 3, DE_LOGITS = 4 };

@@ -500,7 +500,7 @@ def test_suppress_filters_follow_the_oracle(lively, pkg):
 
 
 def test_decode_groups_above_sixteen_use_two_batch_blocks(lively):
-    """A decode group of 17..64 chunks runs every skinny GEMM as blocks of 16 batch rows in one launch; every
+    """A decode group of 17..64 chunks (up to 128) runs every skinny GEMM as blocks of 16 batch rows in one launch; every
     chunk must still decode exactly as it does alone."""
     dims, _, _, ctx = lively
     base = tones(7)
@@ -511,7 +511,7 @@ def test_decode_groups_above_sixteen_use_two_batch_blocks(lively):
         got = ctx.detect_language(ctx.encode_mel(ctx.logmel(base[idx], out_dtype=np.float32)), sot=10, lang_first=20, lang_last=118)
         one = ctx.detect_language(ctx.encode_mel(ctx.logmel(base, out_dtype=np.float32)), sot=10, lang_first=20, lang_last=118)
         assert np.array_equal(got, one[idx]), B           # wm_detect_language at B > 16 (one decode step)
-    for n in (90, 150):                                   # 3 lanes x 30 (two batch blocks), 3 x 50 (four blocks)
+    for n in (90, 150, 330):                              # 3 lanes x 30 (two batch blocks), 3 x 50 (four), 3 x 110 (seven)
         idx = [(5 * i + 1) % 7 for i in range(n)]
         got, lens = ctx.transcribe_greedy(base[idx], prompt, 12)
         assert np.array_equal(got, want[idx]) and np.all(lens == 12), n
