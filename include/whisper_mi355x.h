@@ -135,6 +135,11 @@ int wm_decode_logits(wm_ctx *ctx, const int32_t *tokens, int B, int T, const flo
 int wm_detect_language(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first,
                        int32_t lang_last, int32_t *lang_idx, wm_mem mem);
 
+/* Same step, additionally returning the language probabilities of openai-whisper's detect_language() [3p]: softmax over
+ * the language-token logits only.  probs: f32 [B][lang_last - lang_first + 1], same memory space as xa / lang_idx. */
+int wm_detect_language_probs(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first,
+                             int32_t lang_last, int32_t *lang_idx, float *probs, wm_mem mem);
+
 /* New surface asked for by BASELINE.json (not in the reference): front end + encoder +
  * KV-cached greedy decode of B independent 30 s chunks.  Any B >= 1: the call is cut into balanced
  * decode groups (8 .. 128 chunks) that run concurrently on up to $WM_LANES (default 3) weight-sharing

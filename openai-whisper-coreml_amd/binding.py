@@ -303,6 +303,19 @@ class Context:
                                                      lang_last, _ptr(idx), WM_MEM_HOST))
         return idx
 
+    def detect_language_probs(self, xa, sot=50258, lang_first=50259, lang_last=50357):
+        """(lang_idx [B], probs [B][n_lang]): openai-whisper detect_language() -- softmax over the language tokens."""
+        xa = np.ascontiguousarray(xa, dtype=np.float32)
+        Bn = xa.shape[0]
+        idx = np.empty(Bn, dtype=np.int32)
+        probs = np.empty((Bn, lang_last - lang_first + 1), dtype=np.float32)
+        self.lib.wm_detect_language_probs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int32,
+                                                      ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                                      ctypes.c_int]
+        _check(self.lib, self.lib.wm_detect_language_probs(self.handle, _ptr(xa), Bn, sot, lang_first, lang_last, _ptr(idx),
+                                                           _ptr(probs), WM_MEM_HOST))
+        return idx, probs
+
     def set_suppress(self, suppress=(), suppress_first=()):
         """openai-whisper decode() logit filters for transcribe_greedy: `suppress` ids are never generated
         (SuppressTokens), `suppress_first` ids additionally not as the first generated token (SuppressBlank)."""

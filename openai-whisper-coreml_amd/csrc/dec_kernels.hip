@@ -1014,6 +1014,38 @@ int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles,
     return WM_OK;
 }
 
+// softmax over logits[b][first .. first+n) -> probs[b][n] (openai-whisper detect_language: language-token probabilities)
+namespace {
+__global__ __launch_bounds__(128) void range_softmax_kernel(const float *__restrict__ logits, long ldo, int first, int n,
+                                                            float *__restrict__ probs) {
+    __shared__ float red[2];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *row = logits + (long)b * ldo + first;
+    float m = -1e30f;
+    for (int i = tid; i < n; i += 128) m = fmaxf(m, row[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(red[0], red[1]);
+    __syncthreads();
+    float s = 0.f;
+    for (int i = tid; i < n; i += 128) s += __expf(row[i] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1]);
+    for (int i = tid; i < n; i += 128) probs[(long)b * n + i] = __expf(row[i] - m) * inv;
+}
+}  // namespace
+
+int wm_range_softmax(wm_ctx *ctx, const float *logits, long ldo, int B, int first, int n, float *probs) {
+    range_softmax_kernel<<<B, 128, 0, ctx->stream>>>(logits, ldo, first, n, probs);
+    WM_HIP(hipGetLastError());
+    return WM_OK;
+}
+
 int wm_fill_synthetic(wm_ctx *ctx, const WmTensor &t, uint32_t seed, int tensor_id) {
     if (t.kind == 4) return WM_OK;  // sinusoids are computed on the host (model.cpp)
     const unsigned key = [&] {

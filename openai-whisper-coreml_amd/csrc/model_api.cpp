@@ -197,8 +197,22 @@ extern "C" int wm_decode_logits(wm_ctx *ctx, const int32_t *tokens, int B, int T
     return rc;
 }
 
+static int detect_language_impl(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first, int32_t lang_last,
+                                int32_t *lang_idx, float *probs, wm_mem mem);
+
 extern "C" int wm_detect_language(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first,
                                   int32_t lang_last, int32_t *lang_idx, wm_mem mem) {
+    return detect_language_impl(ctx, xa, B, sot, lang_first, lang_last, lang_idx, nullptr, mem);
+}
+
+extern "C" int wm_detect_language_probs(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first,
+                                        int32_t lang_last, int32_t *lang_idx, float *probs, wm_mem mem) {
+    WM_REQUIRE(probs != nullptr, WM_ERR_INVALID, "null pointer");
+    return detect_language_impl(ctx, xa, B, sot, lang_first, lang_last, lang_idx, probs, mem);
+}
+
+static int detect_language_impl(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first, int32_t lang_last,
+                                int32_t *lang_idx, float *probs, wm_mem mem) {
     WM_MODEL(ctx);
     WM_REQUIRE(xa && lang_idx, WM_ERR_INVALID, "null pointer");
     WM_REQUIRE(B >= 1 && B <= WM_DEC_MAXB, WM_ERR_INVALID, "B must be 1..%d", WM_DEC_MAXB);
@@ -212,9 +226,21 @@ extern "C" int wm_detect_language(wm_ctx *ctx, const float *xa, int B, int32_t s
     WM_HIP(hipStreamSynchronize(ctx->stream));                              // fences `sots`
     WM_TRY(wm_model_set_pos(ctx, 0));
     WM_TRY(wm_model_embed_first(ctx, B));
-    WM_TRY(wm_model_decode_step(ctx, B, false, lang_first, lang_last));     // :36-37
+    WM_TRY(wm_model_decode_step(ctx, B, probs != nullptr, lang_first, lang_last));     // :36-37
     WM_TRY(wm_argmax_embed(ctx, m->dargmax, m->vpad / 16, B, nullptr, nullptr, 0, m->dresult, lang_first, nullptr,
                            nullptr, 0, 0, nullptr, nullptr));               // :38
+    if (probs) {  // openai-whisper detect_language(): softmax over the language-token logits only
+        const int n_lang = lang_last - lang_first + 1;
+        float *d_probs = probs;
+        char *st = nullptr;
+        if (mem == WM_MEM_HOST) {
+            WM_TRY(io_stage(ctx, (size_t)B * n_lang * 4, &st));
+            d_probs = (float *)st;
+        }
+        WM_TRY(wm_range_softmax(ctx, m->dlogits, m->vpad, B, lang_first, n_lang, d_probs));
+        if (mem == WM_MEM_HOST)
+            WM_HIP(hipMemcpyAsync(probs, d_probs, (size_t)B * n_lang * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     std::vector<int32_t> res(B);
     WM_HIP(hipMemcpyAsync(res.data(), m->dresult, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));

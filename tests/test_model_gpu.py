@@ -181,6 +181,13 @@ def test_detect_language_mirrors_swift(tiny):
     assert got.shape == (3,) and got.min() >= 0 and got.max() <= 98
     for b in range(3):
         _check_choice(conf[b], int(got[b]))
+    # openai-whisper detect_language(): probabilities = softmax over the language-token logits only
+    idx, probs = ctx.detect_language_probs(xa, sot=10, lang_first=20, lang_last=118)
+    assert np.array_equal(idx, got) and probs.shape == (3, 99)
+    assert np.allclose(probs.sum(axis=1), 1.0, atol=1e-5) and np.array_equal(probs.argmax(axis=1), idx)
+    ex = np.exp(conf - conf.max(axis=1, keepdims=True))
+    want = ex / ex.sum(axis=1, keepdims=True)
+    assert np.abs(probs - want).max() <= 2e-3, np.abs(probs - want).max()
 
 
 def test_greedy_transcribe_end_to_end(tiny):
