@@ -162,6 +162,16 @@ int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int B
  * logits).  Contexts made later with wm_clone inherit the filter; existing clones must be set themselves. */
 int wm_set_suppress(wm_ctx *ctx, const int32_t *suppress, int n, const int32_t *suppress_first, int n_first);
 
+/* openai-whisper's ApplyTimestampRules (whisper/decoding.py [3p]) for wm_transcribe_greedy, i.e. decoding WITH
+ * timestamps (prompt without <|notimestamps|>): timestamps come in pairs, never decrease, the transcript opens with a
+ * timestamp no later than max_initial_timestamp_index (e.g. 50 = 1.0 s; < 0: unlimited), and a timestamp is forced
+ * whenever the summed probability of the admissible timestamps exceeds the best admissible text token.
+ *   timestamp_begin : id of <|0.00|> (50364; 50365 for large-v3);  eot : <|endoftext|>.
+ * Evaluated inside the fused logits / arg-max kernels; combine with wm_set_suppress (which should list <|notimestamps|>).
+ * enable = 0 switches the rules off.  Same inheritance as wm_set_suppress. */
+int wm_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t timestamp_begin, int32_t eot,
+                           int32_t max_initial_timestamp_index);
+
 /* ------------------------------------------------------------ device memory helpers --- */
 /* For callers that keep inputs resident in HBM (bench.py; a Swift host would use them to
  * avoid the 5.7 MB/chunk PCIe round trip of the reference ABI). */

@@ -325,6 +325,12 @@ class Context:
         _check(self.lib, self.lib.wm_set_suppress(self.handle, _ptr(a) if a.size else None, int(a.size),
                                                   _ptr(b) if b.size else None, int(b.size)))
 
+    def set_timestamp_rules(self, enable, timestamp_begin=0, eot=0, max_initial=-1):
+        """openai-whisper ApplyTimestampRules for transcribe_greedy (decoding with timestamps)."""
+        self.lib.wm_set_timestamp_rules.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int32,
+                                                    ctypes.c_int32]
+        _check(self.lib, self.lib.wm_set_timestamp_rules(self.handle, 1 if enable else 0, timestamp_begin, eot, max_initial))
+
     def transcribe_greedy(self, pcm, prompt, max_new, eot=-1, mem=WM_MEM_HOST, pcm_dtype=None, B=None):
         """pcm: host array [B][480000] (int16/float32/float64), or a device pointer
         (c_void_p) with pcm_dtype and B given when mem == WM_MEM_DEVICE."""

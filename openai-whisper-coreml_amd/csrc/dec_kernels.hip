@@ -19,6 +19,7 @@
 //   * the decode position lives in HBM (*pos_ptr) and is advanced by the arg-max kernel, so
 //     ONE captured hipGraph of the whole step replays for every position.
 #include <stdlib.h>
+#include <string.h>
 
 #include "model.h"
 
@@ -71,6 +72,7 @@ struct DecGemvDev {
     int arg_first, arg_last;
     const unsigned *mask;  // DE_LOGITS: suppressed-token bitmaps [2][mask_words] or null
     int mask_words, mask_first_pos;
+    WmTsDev ts;            // DE_LOGITS: timestamp rules (ts.rng == null: off)
     const char *pf_ptr;   // next GEMV's weights: extra workgroups pull them into this XCD's L2
     long pf_tile_bytes;  // bytes of one 16-row weight tile of that matrix
     int pf_tiles;
@@ -134,6 +136,11 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
         if (p.stats_in) p.stats_in += (long)blk * p.stats_stride;
         if (p.stats_out) p.stats_out += (long)blk * p.stats_stride;
         if (p.tilemax) p.tilemax += r0 * p.n_tiles;
+        if (p.ts.rng) {
+            p.ts.rng += r0 * 4;
+            p.ts.key_ts += r0 * p.n_tiles;
+            p.ts.lse += r0 * p.n_tiles * 2;
+        }
         p.B -= (int)r0;
     }
     if (p.B > 16) p.B = 16;
@@ -169,12 +176,22 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
     float bvs = 0.f, xold[4] = {0.f, 0.f, 0.f, 0.f};
     int pos = 0;
     unsigned mword0 = 0u, mword1 = 0u;
+    int4 trng[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) trng[r] = make_int4(0, 0, 0, 0);
     if (wave == 0) {  // wave-uniform
         if (p.bias) bvs = p.bias[nc];
         if (p.pos_ptr) pos = *p.pos_ptr;
         if (EPI == DE_LOGITS && p.mask) {
             mword0 = p.mask[nc >> 5];
             mword1 = p.mask[p.mask_words + (nc >> 5)];
+        }
+        if (EPI == DE_LOGITS && p.ts.rng) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int b = kq * 4 + r;
+                trng[r] = *(const int4 *)(p.ts.rng + (b < p.B ? b : p.B - 1) * 4);
+            }
         }
         if (EPI == DE_RESID) {
 #pragma unroll
@@ -324,6 +341,36 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
     for (int r = 0; r < 4; ++r) {
         const int b = kq * 4 + r;
         const float v = acc[r] + bvs;
+        if (EPI == DE_LOGITS && p.ts.rng) {
+            // timestamp rules: best allowed text token, best allowed timestamp, and the (max, sum exp) partial of the
+            // allowed timestamps of this tile (only tiles that reach into the timestamp range carry the last two)
+            const unsigned mw = (pos == p.mask_first_pos) ? mword1 : mword0;
+            const bool ok = b < p.B && nvalid && !((mw >> (n & 31)) & 1u);
+            const bool in_text = ok && n >= trng[r].x && n < trng[r].y;
+            const bool in_ts = ok && n >= trng[r].z && n < trng[r].w;
+            unsigned long long kt = in_text ? argmax_key(v, n) : 0ull, ks = in_ts ? argmax_key(v, n) : 0ull;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const unsigned long long a = __shfl_xor(kt, o), c = __shfl_xor(ks, o);
+                kt = a > kt ? a : kt;
+                ks = c > ks ? c : ks;
+            }
+            if (b < p.B && nrow == 0) p.tilemax[(long)b * p.n_tiles + tile] = kt;
+            if (n0 + 16 > p.ts.ts_begin) {  // workgroup-uniform
+                float mx = in_ts ? v : -1e30f;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                float se = in_ts ? __expf(v - mx) : 0.f;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o);
+                if (b < p.B && nrow == 0) {
+                    p.ts.key_ts[(long)b * p.n_tiles + tile] = ks;
+                    *(float2 *)(p.ts.lse + ((long)b * p.n_tiles + tile) * 2) = make_float2(mx, se);
+                }
+            }
+            if (b < p.B && nvalid && p.out_f32) p.out_f32[(long)b * p.ldo + n] = v;
+            continue;
+        }
         if (EPI == DE_LOGITS) {
             // arg-max over [arg_first, arg_last], first maximal index wins (Whisper.swift:38)
             unsigned long long key = 0ull;
@@ -704,7 +751,8 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
                                                              int *__restrict__ result, int arg_first,
                                                              const bf16_t *__restrict__ emb,
                                                              const float *__restrict__ pemb, int d, int n_ctx,
-                                                             float *__restrict__ x, float *__restrict__ stats_out) {
+                                                             float *__restrict__ x, float *__restrict__ stats_out,
+                                                             WmTsDev ts) {
     __shared__ int tok_s[WM_DEC_MAXB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pos = pos_ptr ? *pos_ptr : 0;
@@ -726,8 +774,59 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
             const unsigned long long ok = __shfl_xor(key, o);
             key = ok > key ? ok : key;
         }
+        if (ts.rng) {
+            // `key` is the best allowed TEXT token.  Merge the timestamp tiles: best allowed timestamp and
+            // log-sum-exp of the allowed timestamps; a timestamp is forced when that exceeds the best text logit
+            // (ApplyTimestampRules: "if sum of probability over timestamps is above any other token, sample timestamp").
+            const int t_first = ts.ts_begin >> 4;
+            unsigned long long kts = 0ull;
+            float M = -1e30f;
+            for (int t = t_first + lane; t < n_tiles; t += 64) {
+                const unsigned long long k2 = ts.key_ts[(long)b * n_tiles + t];
+                kts = k2 > kts ? k2 : kts;
+                M = fmaxf(M, ts.lse[((long)b * n_tiles + t) * 2]);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long ok = __shfl_xor(kts, o);
+                kts = ok > kts ? ok : kts;
+                M = fmaxf(M, __shfl_xor(M, o));
+            }
+            float S = 0.f;
+            for (int t = t_first + lane; t < n_tiles; t += 64) {
+                const float2 ms = *(const float2 *)(ts.lse + ((long)b * n_tiles + t) * 2);
+                S += ms.y * __expf(ms.x - M);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) S += __shfl_xor(S, o);
+            unsigned u = (unsigned)(key >> 32);
+            u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;  // inverse of argmax_key's order-preserving map
+            const float text_best = key ? __uint_as_float(u) : -1e30f;
+            const float lse = S > 0.f ? M + __logf(S) : -1e30f;
+            if (kts != 0ull && (key == 0ull || lse > text_best)) key = kts;   // timestamps only
+            else key = kts > key ? kts : key;                                  // arg-max over everything allowed
+        }
         if (lane == 0) {
             const int tok = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+            if (ts.rng && pos + 1 >= n_prompt) {
+                // the token at index pos + 1 was sampled: advance the history and derive the ranges of the next position
+                int *hs = ts.hist + b * 4;
+                const int n_s = hs[0] + 1;
+                const bool prev_ts = hs[0] < 1 || hs[1] != 0;  // penultimate_was_timestamp = len(seq) < 2 or seq[-2] >= begin
+                const bool last_ts = tok >= ts.ts_begin;
+                const int last_val = last_ts ? tok : hs[3];
+                hs[0] = n_s; hs[2] = hs[1]; hs[1] = last_ts ? 1 : 0; hs[3] = last_val;
+                int text_lo = 0, text_hi = ts.ts_begin, ts_lo = ts.ts_begin, ts_hi = ts.n_vocab;
+                if (last_ts) {
+                    if (prev_ts) ts_hi = ts_lo;        // a pair was just closed: the next token is not a timestamp
+                    else text_lo = ts.eot;             // an opening timestamp needs its partner (or <|endoftext|>)
+                }
+                if (last_val >= 0) {                   // timestamps never decrease (and advance unless closing a pair)
+                    const int floor_ts = (last_ts && !prev_ts) ? last_val : last_val + 1;
+                    ts_lo = floor_ts > ts_lo ? floor_ts : ts_lo;
+                }
+                *(int4 *)(ts.rng + b * 4) = make_int4(text_lo, text_hi, ts_lo, ts_hi);
+            }
             int nxt = tok;
             if (seq) {
                 if (pos + 1 >= n_prompt) seq[(pos + 1) * B + b] = tok;
@@ -859,6 +958,7 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     p.kcache = a.kcache; p.vcache = a.vcache; p.pos_ptr = a.pos_ptr; p.n_ctx = a.n_ctx; p.n_head = a.n_head;
     p.ldo = a.ldo; p.tilemax = a.argmax; p.arg_first = a.arg_first; p.arg_last = a.arg_last;
     p.mask = a.mask; p.mask_words = a.mask_words; p.mask_first_pos = a.mask_first_pos;
+    p.ts = a.ts;
     const int nblk = (a.B + 15) / 16;
     p.n_tiles = (a.N + 15) / 16;
     p.n_tiles_pad = nblk > 1 ? (p.n_tiles + 7) / 8 * 8 : p.n_tiles;  // (tile, block) decode in the kernel needs rows of 8
@@ -1006,10 +1106,32 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
 
 int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
                     int n_prompt, int *result, int arg_first, const bf16_t *emb, const float *pemb, int d, int n_ctx,
-                    float *x, float *stats_out) {
+                    float *x, float *stats_out, const WmTsDev *ts) {
     WmProfScope ps(&ctx->prof, "argmax_embed", ctx->stream);
+    WmTsDev t;
+    memset(&t, 0, sizeof(t));
+    if (ts) t = *ts;
     argmax_embed_kernel<<<1, 1024, 0, ctx->stream>>>(tilemax, n_tiles, B, seq, pos_ptr, n_prompt, result, arg_first,
-                                                     emb, pemb, d, n_ctx, x, stats_out);
+                                                     emb, pemb, d, n_ctx, x, stats_out, t);
+    WM_HIP(hipGetLastError());
+    return WM_OK;
+}
+
+namespace {
+// state before the first sampled token: no text token may open the transcript (timestamps on), the first timestamp
+// is at most max_initial; history empty
+__global__ void ts_init_kernel(WmTsDev ts, int B) {
+    const int b = threadIdx.x;
+    if (b >= B) return;
+    const int hi = ts.max_initial >= 0 && ts.ts_begin + ts.max_initial + 1 < ts.n_vocab ? ts.ts_begin + ts.max_initial + 1
+                                                                                         : ts.n_vocab;
+    *(int4 *)(ts.rng + b * 4) = make_int4(0, 0, ts.ts_begin, hi);
+    *(int4 *)(ts.hist + b * 4) = make_int4(0, 0, 1, -1);
+}
+}  // namespace
+
+int wm_ts_init(wm_ctx *ctx, const WmTsDev &ts, int B) {
+    ts_init_kernel<<<1, WM_DEC_MAXB, 0, ctx->stream>>>(ts, B);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

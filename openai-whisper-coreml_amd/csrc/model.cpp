@@ -56,8 +56,34 @@ static int alloc_decode_buffers(WmModel *m, hipStream_t s) {
     WM_TRY(dalloc_t(m, &m->dresult, WM_DEC_MAXB, s));
     WM_TRY(dalloc_t(m, &m->dseq, (size_t)WM_DEC_MAXB * (D.n_text_ctx + 1), s));
     WM_TRY(dalloc_t(m, &m->dpos, 4, s));
+    WM_TRY(dalloc_t(m, &m->dts_rng, (size_t)WM_DEC_MAXB * 4, s));
+    WM_TRY(dalloc_t(m, &m->dts_hist, (size_t)WM_DEC_MAXB * 4, s));
+    WM_TRY(dalloc_t(m, &m->dts_key, (size_t)WM_DEC_MAXB * (m->vpad / 16), s));
+    WM_TRY(dalloc_t(m, &m->dts_lse, (size_t)WM_DEC_MAXB * (m->vpad / 16) * 2, s));
     WM_TRY(dalloc_t(m, &m->dmask, (size_t)2 * (m->vpad / 32), s));
     WM_HIP(hipMemsetAsync(m->dmask, 0, (size_t)2 * (m->vpad / 32) * 4, s));
+    return WM_OK;
+}
+
+WmTsDev wm_model_ts_dev(const WmModel *m) {
+    WmTsDev t;
+    memset(&t, 0, sizeof(t));
+    if (!m->ts_on) return t;
+    t.rng = m->dts_rng; t.hist = m->dts_hist; t.key_ts = m->dts_key; t.lse = m->dts_lse;
+    t.ts_begin = m->ts_begin; t.eot = m->ts_eot; t.n_vocab = m->dims.n_vocab; t.max_initial = m->ts_max_initial;
+    return t;
+}
+
+int wm_model_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t ts_begin, int32_t eot, int32_t max_initial) {
+    WmModel *m = ctx->model;
+    WM_REQUIRE(m, WM_ERR_STATE, "context has no model");
+    if (enable) {
+        const int V = m->dims.n_vocab;
+        WM_REQUIRE(ts_begin > 0 && ts_begin < V && eot >= 0 && eot < ts_begin, WM_ERR_INVALID,
+                   "timestamp rules: need 0 <= eot < timestamp_begin < n_vocab (%d)", V);
+        m->ts_begin = ts_begin; m->ts_eot = eot; m->ts_max_initial = max_initial;
+    }
+    m->ts_on = enable != 0;
     return WM_OK;
 }
 
@@ -216,6 +242,7 @@ int wm_model_clone(wm_ctx *child, const wm_ctx *parent) {
     WM_TRY(alloc_decode_buffers(m, child->stream));
     WM_HIP(hipMemcpyAsync(m->dmask, pm->dmask, (size_t)2 * (m->vpad / 32) * 4, hipMemcpyDeviceToDevice, child->stream));
     m->mask_on = pm->mask_on;
+    m->ts_on = pm->ts_on; m->ts_begin = pm->ts_begin; m->ts_eot = pm->ts_eot; m->ts_max_initial = pm->ts_max_initial;
     WM_HIP(hipStreamSynchronize(child->stream));
     return WM_OK;
 }
@@ -475,7 +502,7 @@ int wm_model_set_pos(wm_ctx *ctx, int pos) {
     return WM_OK;
 }
 
-int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, int arg_last, int mask_first_pos) {
+int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, int arg_last, int mask_first_pos, bool use_ts) {
     WmModel *m = ctx->model;
     const wm_dims &D = m->dims;
     const int d = D.n_text_state, H = D.n_text_head, T = D.n_text_ctx, S = 1500;
@@ -544,6 +571,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         if (mask_first_pos >= 0) {
             a.mask = m->dmask; a.mask_words = m->vpad / 32; a.mask_first_pos = mask_first_pos; a.pos_ptr = m->dpos;
         }
+        if (use_ts) a.ts = wm_model_ts_dev(m);
         WM_TRY(wm_dec_gemv(ctx, a));
     }
     return WM_OK;
@@ -554,9 +582,10 @@ int wm_model_embed_first(wm_ctx *ctx, int B) {
     return wm_dec_embed(ctx, m->dseq, m->dpos, B, m->tok_emb, m->dec_pos, m->dims.n_text_state, m->dx, m->dstats);
 }
 
-int wm_model_close_step(wm_ctx *ctx, int B, int n_prompt, bool write_seq, int *result, int arg_first) {
+int wm_model_close_step(wm_ctx *ctx, int B, int n_prompt, bool write_seq, int *result, int arg_first, bool use_ts) {
     WmModel *m = ctx->model;
+    const WmTsDev t = wm_model_ts_dev(m);
     return wm_argmax_embed(ctx, m->dargmax, m->vpad / 16, B, write_seq ? m->dseq : nullptr, m->dpos, n_prompt, result,
                            arg_first, m->tok_emb, m->dec_pos, m->dims.n_text_state, m->dims.n_text_ctx, m->dx,
-                           m->dstats);
+                           m->dstats, use_ts ? &t : nullptr);
 }

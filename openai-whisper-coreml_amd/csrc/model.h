@@ -60,6 +60,20 @@ struct WmTensor {
     bool set = false;
 };
 
+// openai-whisper's ApplyTimestampRules (whisper/decoding.py [3p]) evaluated inside the fused logits / arg-max kernels.
+// Per sequence the rules reduce to an allowed TEXT range and an allowed TIMESTAMP range of token ids for the next
+// position (rng), maintained by the arg-max kernel from a 4-int history (hist), plus one comparison: if the summed
+// probability of the allowed timestamps exceeds the best allowed text token, a timestamp is forced -- the logits kernel
+// therefore emits, per 16-column tile, the best text key, the best timestamp key and a (max, sum exp) partial of the
+// timestamp columns.
+struct WmTsDev {
+    int *rng;                     // [B][4] text_lo, text_hi, ts_lo, ts_hi for the next position; null = rules off
+    int *hist;                    // [B][4] n_sampled, last_is_ts, prev_is_ts, last_ts
+    unsigned long long *key_ts;   // [B][n_tiles] best allowed timestamp per tile (tiles >= ts_begin / 16 only)
+    float *lse;                   // [B][n_tiles][2] (max, sum exp(v - max)) over the allowed timestamps of the tile
+    int ts_begin, eot, n_vocab, max_initial;  // max_initial: index of the largest first timestamp, < 0 = unlimited
+};
+
 struct WmModel {
     wm_dims dims;
     bool finalized = false;
@@ -110,6 +124,12 @@ struct WmModel {
     int graph_B = 0, graph_n_prompt = 0, graph_cap_b = 0, graph_mask = 0;
     unsigned *dmask = nullptr;   // [2][vpad/32] suppressed-token bitmaps (wm_set_suppress); [1] = first generated token
     bool mask_on = false;
+    // timestamp rules (wm_set_timestamp_rules): per-sequence state and per-tile partials, see WmTsDev
+    bool ts_on = false;
+    int ts_begin = 0, ts_eot = 0, ts_max_initial = -1;
+    int *dts_rng = nullptr, *dts_hist = nullptr;
+    unsigned long long *dts_key = nullptr;
+    float *dts_lse = nullptr;
     void *pcm_stage = nullptr;  // host-pointer staging for wm_transcribe_greedy
     size_t pcm_stage_bytes = 0;
     float *io_stage = nullptr;  // staging for host-pointer model calls
@@ -134,12 +154,16 @@ int wm_model_decode_begin(wm_ctx *ctx, int B);
 // embedded input of that position in m->dx (+ m->dstats): wm_model_embed_first for the first
 // position, afterwards produced by wm_model_close_step.  Ends with logits -> per-tile arg-max over
 // [arg_first, arg_last] (m->dargmax); want_logits additionally stores f32 logits in m->dlogits.
-int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, int arg_last, int mask_first_pos = -1);
+int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, int arg_last, int mask_first_pos = -1,
+                         bool use_ts = false);
+// the device view of the context's timestamp-rule state (rng == null when the rules are off)
+WmTsDev wm_model_ts_dev(const WmModel *m);
+int wm_model_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t ts_begin, int32_t eot, int32_t max_initial);
 // mask_first_pos >= 0: apply the suppress bitmaps, the first-token one at decode position mask_first_pos
 int wm_model_set_suppress(wm_ctx *ctx, const int32_t *ids, int n, const int32_t *first_ids, int n_first);
 int wm_model_embed_first(wm_ctx *ctx, int B);
 // arg-max reduce + write next token (positions >= n_prompt) + embed next position + advance *dpos
-int wm_model_close_step(wm_ctx *ctx, int B, int n_prompt, bool write_seq, int *result, int arg_first);
+int wm_model_close_step(wm_ctx *ctx, int B, int n_prompt, bool write_seq, int *result, int arg_first, bool use_ts = false);
 int wm_model_set_pos(wm_ctx *ctx, int pos);
 
 // ---------------------------------------------------------------- kernel launchers ----
@@ -207,6 +231,7 @@ struct DecGemvArgs {
     // *pos_ptr == mask_first_pos only (first generated token); null = no filter
     const unsigned *mask;
     int mask_words, mask_first_pos;
+    WmTsDev ts;  // DE_LOGITS: timestamp rules (ts.rng == null: off)
     // optional L2 warm-up of the NEXT skinny GEMV's weights ([pf_rows][pf_k] bf16, WL_TILED)
     const bf16_t *pf_ptr;
     int pf_rows, pf_k;
@@ -231,6 +256,8 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
 // partial statistics) when x != null; then *pos_ptr += 1.  seq / pos_ptr / result / x may be null.
 int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
                     int n_prompt, int *result, int arg_first, const bf16_t *emb, const float *pemb, int d, int n_ctx,
-                    float *x, float *stats_out);
+                    float *x, float *stats_out, const WmTsDev *ts = nullptr);
+// initial timestamp-rule state of B sequences (before the first sampled token)
+int wm_ts_init(wm_ctx *ctx, const WmTsDev &ts, int B);
 int wm_range_softmax(wm_ctx *ctx, const float *logits, long ldo, int B, int first, int n, float *probs);
 int wm_fill_synthetic(wm_ctx *ctx, const WmTensor &t, uint32_t seed, int tensor_id);

@@ -58,6 +58,15 @@ extern "C" int wm_set_suppress(wm_ctx *ctx, const int32_t *suppress, int n, cons
     for (wm_ctx *lane : ctx->lanes) WM_TRY(wm_model_set_suppress(lane, suppress, n, suppress_first, n_first));
     return WM_OK;
 }
+extern "C" int wm_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t timestamp_begin, int32_t eot,
+                                      int32_t max_initial_timestamp_index) {
+    WM_MODEL(ctx);
+    (void)m;
+    WM_TRY(wm_model_set_timestamp_rules(ctx, enable, timestamp_begin, eot, max_initial_timestamp_index));
+    for (wm_ctx *lane : ctx->lanes)
+        WM_TRY(wm_model_set_timestamp_rules(lane, enable, timestamp_begin, eot, max_initial_timestamp_index));
+    return WM_OK;
+}
 extern "C" int wm_get_dims(const wm_ctx *ctx, wm_dims *out) {
     WM_REQUIRE(ctx && out, WM_ERR_INVALID, "null pointer");
     WM_REQUIRE(ctx->model, WM_ERR_STATE, "context has no model");
@@ -321,8 +330,9 @@ int lane_prefill(LaneJob &j, const void *pcm, wm_dtype pcm_dtype, const int32_t 
     WM_TRY(wm_model_encode_dev(c, m->mel_f32, Bg, nullptr));
     WM_TRY(wm_model_cross_kv(c, Bg));
     WM_HIP(hipEventRecord(j.ev[2], c->stream));
-    // 3. embedding of the first prompt token
+    // 3. embedding of the first prompt token (+ the initial timestamp-rule state)
     WM_TRY(wm_model_embed_first(c, Bg));
+    if (m->ts_on) WM_TRY(wm_ts_init(c, wm_model_ts_dev(m), Bg));
     return WM_OK;
 }
 
@@ -332,15 +342,15 @@ int lane_prefill(LaneJob &j, const void *pcm, wm_dtype pcm_dtype, const int32_t 
 int lane_graph(LaneJob &j, int n_prompt) {
     wm_ctx *c = j.c;
     WmModel *m = c->model;
-    const int mk = m->mask_on ? 1 : 0;
+    const int mk = (m->mask_on ? 1 : 0) | (m->ts_on ? 2 : 0);
     if (m->graph_exec && m->graph_B == j.Bg && m->graph_n_prompt == n_prompt && m->graph_cap_b == m->cap_b &&
         m->graph_mask == mk)
         return WM_OK;
     if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
     if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
     WM_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    int crc = wm_model_decode_step(c, j.Bg, false, 0, m->dims.n_vocab - 1, m->mask_on ? n_prompt - 1 : -1);
-    if (crc == WM_OK) crc = wm_model_close_step(c, j.Bg, n_prompt, true, nullptr, 0);
+    int crc = wm_model_decode_step(c, j.Bg, false, 0, m->dims.n_vocab - 1, m->mask_on ? n_prompt - 1 : -1, m->ts_on);
+    if (crc == WM_OK) crc = wm_model_close_step(c, j.Bg, n_prompt, true, nullptr, 0, m->ts_on);
     hipError_t ce = hipStreamEndCapture(c->stream, &m->graph);
     if (crc != WM_OK) return crc;
     WM_HIP(ce);
@@ -407,8 +417,8 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
                     WM_HIP(hipGraphLaunch(j.c->model->graph_exec, j.c->stream));
                 } else {
                     WM_TRY(wm_model_decode_step(j.c, j.Bg, false, 0, D.n_vocab - 1,
-                                                j.c->model->mask_on ? n_prompt - 1 : -1));
-                    WM_TRY(wm_model_close_step(j.c, j.Bg, n_prompt, true, nullptr, 0));
+                                                j.c->model->mask_on ? n_prompt - 1 : -1, j.c->model->ts_on));
+                    WM_TRY(wm_model_close_step(j.c, j.Bg, n_prompt, true, nullptr, 0, j.c->model->ts_on));
                 }
             }
         for (int l = 0; l < nl; ++l) {

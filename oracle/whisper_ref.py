@@ -111,7 +111,36 @@ def detect_language(sd, dims, xa, sot=50258, lang_first=50259, lang_last=50357):
 
 
 @torch.no_grad()
-def greedy(sd, dims, xa, prompt, max_new, eot=-1, suppress=(), suppress_first=()):
+def timestamp_filter(row, seq, ts_begin, eot, max_initial=-1, sum_rule=True):
+    """openai-whisper ApplyTimestampRules (whisper/decoding.py [3p]) for ONE sequence: `row` = logits after the
+    suppress filters (1-D float tensor, modified in place), `seq` = the tokens sampled so far.  Returns
+    (forced, gap): whether the summed timestamp probability forced a timestamp, and logsumexp(timestamps) - max(text)."""
+    last_was = len(seq) >= 1 and seq[-1] >= ts_begin
+    penult = len(seq) < 2 or seq[-2] >= ts_begin
+    if last_was:
+        if penult:
+            row[ts_begin:] = float("-inf")      # has to be non-timestamp
+        else:
+            row[:eot] = float("-inf")           # cannot be normal text tokens
+    tss = [t for t in seq if t >= ts_begin]
+    if tss:
+        last = tss[-1] if (last_was and not penult) else tss[-1] + 1
+        row[ts_begin:last] = float("-inf")      # timestamps shouldn't decrease
+    if len(seq) == 0:
+        row[:ts_begin] = float("-inf")          # suppress generating non-timestamp tokens at the beginning
+        if max_initial is not None and max_initial >= 0:
+            row[ts_begin + max_initial + 1:] = float("-inf")
+    lp = torch.log_softmax(row.float(), dim=-1)
+    ts_lp = torch.logsumexp(lp[ts_begin:], dim=-1)
+    text_lp = lp[:ts_begin].max()
+    forced = bool(ts_lp > text_lp)
+    gap = float(ts_lp - text_lp) if torch.isfinite(ts_lp) and torch.isfinite(text_lp) else float("inf")
+    if forced and sum_rule:   # sum_rule=False: structural rules only (tests use it to judge near-ties of the sum rule)
+        row[:ts_begin] = float("-inf")
+    return forced, gap
+
+
+def greedy(sd, dims, xa, prompt, max_new, eot=-1, suppress=(), suppress_first=(), ts_rules=None):
     """KV-cached greedy decode (the extension BASELINE.json asks for): returns tokens
     [B, max_new] (padded with eot after a stop), lens [B], and the per-step logits (filtered).
     `suppress` / `suppress_first` restate openai-whisper's SuppressTokens / SuppressBlank logit filters
@@ -162,6 +191,10 @@ def greedy(sd, dims, xa, prompt, max_new, eot=-1, suppress=(), suppress_first=()
             logits[:, list(suppress)] = float("-inf")
         if step == 0 and len(suppress_first):
             logits[:, list(suppress_first)] = float("-inf")
+        if ts_rules is not None:   # dict(ts_begin=, eot=, max_initial=): decoding WITH timestamps
+            for b in range(B):
+                timestamp_filter(logits[b], [int(t) for t in out[b, :step]], ts_rules["ts_begin"], ts_rules["eot"],
+                                 ts_rules.get("max_initial", -1))
         all_logits.append(logits.numpy())
         nxt = logits.argmax(dim=1)
         for b in range(B):

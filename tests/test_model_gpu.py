@@ -522,3 +522,73 @@ def test_decode_groups_above_sixteen_use_two_batch_blocks(lively):
         idx = [(5 * i + 1) % 7 for i in range(n)]
         got, lens = ctx.transcribe_greedy(base[idx], prompt, 12)
         assert np.array_equal(got, want[idx]) and np.all(lens == 12), n
+
+
+def test_timestamp_rules_follow_the_oracle(lively, pkg):
+    """wm_set_timestamp_rules == openai-whisper's ApplyTimestampRules inside the fused logits / arg-max kernels:
+    per-sequence admissible ranges (pairs, monotonic, initial timestamp) + the summed-probability rule."""
+    import torch
+    dims, _, sd, ctx = lively
+    TS, EOT, MAXI, NEW = 900, 890, 20, 24            # tiny vocabulary (1024): timestamps 900..1023, specials 891..899
+    pcm = tones(4)
+    mel = ctx.logmel(pcm, out_dtype=np.float32)
+    prompt = [10, 21, 5]
+    specials = list(range(EOT + 1, TS))
+    ctx.set_suppress(specials, [EOT])
+    ctx.set_timestamp_rules(True, TS, EOT, MAXI)
+    try:
+        got, lens = ctx.transcribe_greedy(pcm, prompt, NEW)
+        # structure: opens with a timestamp <= TS + MAXI; timestamps never decrease; never three timestamps in a row
+        assert np.all(got[:, 0] >= TS) and np.all(got[:, 0] <= TS + MAXI)
+        for b in range(4):
+            ts = [t for t in got[b] if t >= TS]
+            assert all(x <= y for x, y in zip(ts, ts[1:])), (b, ts)
+            isT = [t >= TS for t in got[b]]
+            assert not any(isT[i] and isT[i + 1] and isT[i + 2] for i in range(NEW - 2)), (b, got[b])
+            assert not (set(got[b].tolist()) & set(specials))
+        assert any((got[b] < TS).any() for b in range(4)) and any((got[b, 1:] >= TS).any() for b in range(4))
+        # every choice against the oracle's filtered logits, teacher-forced on the GPU's own history
+        xa = ctx.encode_mel(mel)
+        n_forced = 0
+        for b in range(4):
+            seq = np.concatenate([prompt, got[b]])[None, :-1]
+            ref = R.decode_logits(sd, dims, seq, xa[b:b + 1])[0]
+            for i in range(NEW):
+                row = ref[len(prompt) - 1 + i].clone()
+                row[specials] = float("-inf")
+                if i == 0:
+                    row[EOT] = float("-inf")
+                unforced = row.clone()
+                forced, gap = R.timestamp_filter(row, [int(t) for t in got[b, :i]], TS, EOT, MAXI)
+                n_forced += forced
+                choice = int(got[b, i])
+                if abs(gap) < MARGIN:            # the summed-probability rule is a near-tie: either branch is right
+                    R.timestamp_filter(unforced, [int(t) for t in got[b, :i]], TS, EOT, MAXI, sum_rule=False)
+                    only_ts = unforced.clone()
+                    only_ts[:TS] = float("-inf")
+                    ok = float(only_ts.max() - only_ts[choice]) <= MARGIN or float(unforced.max() - unforced[choice]) <= MARGIN
+                    assert ok, (b, i, choice)
+                else:
+                    _check_choice(row.numpy(), choice)
+        assert n_forced > 0
+        # free-running oracle (its own encoder, its own history) up to the first near-tie
+        want, _, logits = R.greedy(sd, dims, R.encode(sd, dims, mel), prompt, NEW, suppress=specials, suppress_first=[EOT],
+                                   ts_rules=dict(ts_begin=TS, eot=EOT, max_initial=MAXI))
+        agree = 0
+        for b in range(4):
+            for i in range(NEW):
+                fin = logits[b, i][np.isfinite(logits[b, i])]
+                top2 = np.sort(fin)[-2:] if fin.size >= 2 else np.array([0.0, 1.0])
+                if top2[1] - top2[0] < MARGIN or got[b, i] != want[b, i]:
+                    break
+                agree += 1
+        assert agree >= 8, agree
+        # lanes carry the rules and their per-sequence state
+        idx = [i % 4 for i in range(19)]
+        many, _ = ctx.transcribe_greedy(pcm[idx], prompt, NEW)
+        assert np.array_equal(many, got[idx])
+        with pytest.raises(pkg.binding.WhisperError, match="timestamp"):
+            ctx.set_timestamp_rules(True, 5, 7, -1)
+    finally:
+        ctx.set_timestamp_rules(False)
+        ctx.set_suppress([], [])

@@ -85,6 +85,39 @@ def test_suppress_filters_in_the_oracle():
     assert np.array_equal(same, free)
 
 
+def test_timestamp_rules_in_the_oracle():
+    """ApplyTimestampRules restatement on hand-made logits (vocabulary 32: text 0..19, eot 20, timestamps 24..31)."""
+    import torch
+    TS, EOT = 24, 20
+    flat = lambda: torch.zeros(32)
+    # first position: text is forbidden, the first timestamp is at most TS + max_initial
+    row = flat(); forced, _ = R.timestamp_filter(row, [], TS, EOT, max_initial=2)
+    assert torch.isneginf(row[:TS]).all() and torch.isfinite(row[TS:TS + 3]).all() and torch.isneginf(row[TS + 3:]).all()
+    # after text + one timestamp: the pair must be completed (or eot): plain text is forbidden, earlier timestamps too
+    row = flat(); row[3] = 9.0
+    R.timestamp_filter(row, [TS + 1, 5, TS + 4], TS, EOT)
+    assert torch.isneginf(row[:EOT]).all() and torch.isneginf(row[TS:TS + 4]).all() and torch.isfinite(row[TS + 4:]).all()
+    # after a closed pair: no third timestamp in a row
+    row = flat()
+    R.timestamp_filter(row, [TS + 1, 5, TS + 4, TS + 4], TS, EOT, sum_rule=False)
+    assert torch.isneginf(row[TS:]).all() and torch.isfinite(row[:TS]).all()
+    # the summed-probability rule: 8 timestamps at logit 0 outweigh one text token at logit 1 (log 8 > 1) ...
+    row = flat(); row[:TS] = -5.0; row[7] = 1.0
+    forced, gap = R.timestamp_filter(row, [TS + 1, TS + 1, 4], TS, EOT)
+    assert forced and gap > 0 and torch.isneginf(row[:TS]).all()
+    # ... but not one at logit 3 (log 6 < 3; timestamps below the last one are gone)
+    row = flat(); row[:TS] = -5.0; row[7] = 3.0
+    forced, gap = R.timestamp_filter(row, [TS + 1, TS + 1, 4], TS, EOT)
+    assert not forced and gap < 0 and torch.isfinite(row[7]) and torch.isneginf(row[TS:TS + 2]).all()
+    # greedy with the rules: opens with a timestamp, timestamps never decrease
+    dims = dict(R.TINY_DIMS)
+    sd = R.to_torch(_sd(4))
+    mel = np.random.default_rng(3).standard_normal((1, 80, 3000)).astype(np.float32) * 0.5
+    out, _, _ = R.greedy(sd, dims, R.encode(sd, dims, mel), [1, 2], 10, ts_rules=dict(ts_begin=900, eot=890, max_initial=5))
+    ts = [t for t in out[0] if t >= 900]
+    assert 900 <= out[0, 0] <= 905 and all(a <= b for a, b in zip(ts, ts[1:]))
+
+
 def test_model_golden_vectors():
     """Committed fixture (tests/golden/make_model_golden.py): pins the oracle against drift."""
     g = np.load(os.path.join(GOLDEN, "model_golden.npz"))
