@@ -592,3 +592,30 @@ def test_timestamp_rules_follow_the_oracle(lively, pkg):
     finally:
         ctx.set_timestamp_rules(False)
         ctx.set_suppress([], [])
+
+
+def test_full_depth_large_v2_against_the_oracle(pkg):
+    """BASELINE.json configs[3] at full depth (32 + 32 layers, d = 1280, 51 865-row tied embedding), one chunk:
+    encoder output and teacher-forced decoder logits against the torch-fp32 oracle on the GPU's own (bf16-rounded)
+    weights.  The error grows with depth (tiny 2-layer models: 3e-4 .. 1e-3) and stays inside the stated tolerances."""
+    import torch
+    dims = pkg.binding.MODEL_DIMS["large-v2"]
+    ctx = pkg.binding.Context(dims)
+    ctx.init_synthetic(7)
+    ctx.finalize()
+    pcm = np.stack([L.synth_chunk(21)])
+    mel = ctx.logmel(pcm)
+    xa = ctx.encode_mel(mel)
+    sd = R.to_torch({n: ctx.get_tensor(n, s) for n, s, _ in W.tensor_specs(dims)})
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    want = R.encode(sd, dims, mel).numpy()
+    e_enc = R.rel_l2(xa, want)
+    tok = np.array([[50258, 50259, 50359, 50363]], dtype=np.int32)
+    got = ctx.decode_logits(tok, want)
+    ref = R.decode_logits(sd, dims, tok, want).numpy()
+    e_log = R.rel_l2(got, ref)
+    print("large-v2 full depth: encoder rel-L2 %.3e, logits rel-L2 %.3e" % (e_enc, e_log))
+    assert e_enc <= ENC_TOL and e_log <= LOGIT_TOL
+    for t in range(4):
+        _check_choice(ref[0, t], int(got[0, t].argmax()))
+    ctx.close()
