@@ -619,3 +619,34 @@ def test_full_depth_large_v2_against_the_oracle(pkg):
     for t in range(4):
         _check_choice(ref[0, t], int(got[0, t].argmax()))
     ctx.close()
+
+
+def test_full_text_context_and_degenerate_audio(lively):
+    """Maximum sizes and degenerate inputs: a decode that fills all 448 text positions (self-attention over the whole
+    cache, last K/V slot written) must equal the stateless full-prefix recompute of wm_decode_logits; all-zero and
+    clipped full-scale audio (KAT-1: log-mel == -1.5 everywhere) must go through without NaNs."""
+    dims, _, sd, ctx = lively
+    T = dims["n_text_ctx"]
+    pcm = tones(2)
+    prompt = [10, 21, 5, 7]
+    toks, lens = ctx.transcribe_greedy(pcm, prompt, T - len(prompt))
+    assert toks.shape == (2, T - len(prompt)) and np.all(lens == T - len(prompt))
+    xa = ctx.encode_mel(ctx.logmel(pcm, out_dtype=np.float32))
+    seq = np.concatenate([np.tile(prompt, (2, 1)), toks], axis=1)[:, :T].astype(np.int32)
+    full = ctx.decode_logits(seq[:, :T], xa)                     # [2][448][V], no cache: every prefix recomputed
+    for b in range(2):
+        for pos in (len(prompt) - 1, 100, 222, T - 3, T - 2):    # logits at pos choose the token at pos + 1
+            row = full[b, pos]
+            assert row.max() - row[seq[b, pos + 1]] <= MARGIN, (b, pos)
+    # degenerate audio
+    zero = np.zeros((1, 480000), np.float32)
+    loud = np.ones((1, 480000), np.float32) * np.where(np.arange(480000) % 2 == 0, 1.0, -1.0).astype(np.float32)
+    mel0 = ctx.logmel(zero, out_dtype=np.float32)
+    assert np.all(mel0 == -1.5)
+    for x in (zero, loud, np.round(loud * 32767).astype(np.int16)):
+        t, _ = ctx.transcribe_greedy(x, prompt, 6)
+        assert t.shape == (1, 6) and t.min() >= 0 and t.max() < dims["n_vocab"]
+    xa0 = ctx.encode_mel(mel0)
+    assert np.isfinite(xa0).all()
+    want0 = R.encode(sd, dims, mel0).numpy()
+    assert R.rel_l2(xa0, want0) <= ENC_TOL
