@@ -642,7 +642,7 @@ def test_full_text_context_and_degenerate_audio(lively):
     zero = np.zeros((1, 480000), np.float32)
     loud = np.ones((1, 480000), np.float32) * np.where(np.arange(480000) % 2 == 0, 1.0, -1.0).astype(np.float32)
     mel0 = ctx.logmel(zero, out_dtype=np.float32)
-    assert np.all(mel0 == -1.5)
+    assert np.abs(mel0 + 1.5).max() <= 1e-5                      # f32 fast path (the f64 ABI path gives -1.5 exactly, test_frontend_gpu)
     for x in (zero, loud, np.round(loud * 32767).astype(np.int16)):
         t, _ = ctx.transcribe_greedy(x, prompt, 6)
         assert t.shape == (1, 6) and t.min() >= 0 and t.max() < dims["n_vocab"]
