@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <vector>
 
@@ -431,6 +432,9 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
         float wave_ms[3] = {0.f, 0.f, 0.f};
         for (int l = 0; l < nl; ++l) {
             LaneJob &j = jobs[l];
+            // a decode group runs for seconds: poll instead of spinning in hipStreamSynchronize, so that the host threads
+            // of the other lanes / ranks (one process per GPU, several contexts each) keep their cores
+            while (hipStreamQuery(j.c->stream) == hipErrorNotReady) usleep(200);
             WM_HIP(hipStreamSynchronize(j.c->stream));
             for (int b = 0; b < j.Bg; ++b) {
                 int len = max_new;
