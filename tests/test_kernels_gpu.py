@@ -186,3 +186,27 @@ def test_decode_attention_rejects_bad_split(ctx):
     out = np.zeros((1, 64), np.float32)
     assert ctx.lib.wmdbg_dec_attention(ctx.handle, P(q), P(k), P(k), 1, 1, 64, 64, 9, P(out)) == 1
     assert b"nsplit" in ctx.lib.wm_last_error()
+
+
+def test_gemm_256_tile_is_bitwise_equal_to_the_128_tile(ctx):
+    """Race screen for the staggered-phase 256 x 256 kernel (counted vmcnt, asm ds_reads): it accumulates in the same
+    order as the 128 x 128 kernel, so any difference on the same operands is a synchronisation bug, not rounding.
+    (tools/gpu_gemm_race_screen.py is the long version: 1080 comparisons next to a running bench, 0 mismatches.)"""
+    ctx.lib.wmdbg_set_gemm_tile.argtypes = [ctypes.c_int]
+    try:
+        for it in range(3):
+            for (M, N, K) in [(2048, 2048, 1280), (1031, 768, 448), (1536, 1280, 5120)]:
+                rng = np.random.default_rng(17 * it + M + K)
+                A = bf(rng.standard_normal((M, K)))
+                Wt = bf(rng.standard_normal((N, K)) * 0.05)
+                bias = rng.standard_normal(N).astype(np.float32)
+                for epi in (6, 1, 2):
+                    outs = []
+                    for tile in (128, 256):
+                        assert ctx.lib.wmdbg_set_gemm_tile(tile) == 0
+                        C = np.full((M, N), 0.25, np.float32)
+                        assert ctx.lib.wmdbg_gemm(ctx.handle, P(A), P(Wt), P(bias), P(C), M, N, K, epi) == 0
+                        outs.append(C)
+                    assert np.array_equal(outs[0], outs[1]), (it, M, N, K, epi)
+    finally:
+        ctx.lib.wmdbg_set_gemm_tile(0)
