@@ -200,6 +200,7 @@ def main():
     import threading
     ctxs = [ctx] + [ctx.clone() for _ in range(S - 1)]
     gathered = None
+    seen = []   # (steps in the group, tokens) of every finished group: compared after the timed region
 
     def run_steps(n_steps):
         """n_steps batches of nb chunks, S in flight; returns summed stage ms of all steps."""
@@ -235,6 +236,7 @@ def main():
         while finished < n_steps:
             toks, lens, k = done.get()
             finished += k
+            seen.append((k, toks))
             if use_dist:
                 # the only exchange of the whole job: one fixed-stride all-gather of the token streams per group
                 gathered = sharding.gather_tokens(dist, toks, lens, nb * k * world, world, device="cuda")
@@ -259,6 +261,20 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64).cuda()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # every group decoded the same resident chunks: groups of equal size must have produced identical tokens
+    # (bit-level determinism across lanes, graph replays and concurrency), and a smaller group the prefix rows
+    ref_by_k = {}
+    tokens_consistent = True
+    for k, toks in seen:
+        if k not in ref_by_k:
+            ref_by_k[k] = toks
+        elif not np.array_equal(ref_by_k[k], toks):
+            tokens_consistent = False
+    kmax = max(ref_by_k) if ref_by_k else 0
+    for k, toks in ref_by_k.items():
+        if k != kmax and not np.array_equal(toks, ref_by_k[kmax][:toks.shape[0]]):
+            tokens_consistent = False
 
     # for transparency: the same workload with ONE batch in flight (latency of a single batch of nb chunks)
     single_ms = None
@@ -370,6 +386,7 @@ def main():
             "decoder_tok_per_s": (S * nb * world * max_new) / max(stage_s[2], 1e-9),   # S pipelines decode concurrently
             "tok_per_s_end_to_end": (nb * world * max_new * args.steps) / dt,
             "inflight_batches_per_gpu": S * F,
+            "tokens_consistent_across_groups": tokens_consistent,
             "single_batch_latency_ms": single_ms,
             "value_one_batch_in_flight": (30.0 * nb / (single_ms * 1e-3)) if single_ms else None,
             "decoder_ms_per_step": stage_s[2] * 1e3 / dec_steps,
