@@ -23,6 +23,7 @@ import ctypes
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -193,55 +194,35 @@ def main():
     prompt = [sot, sot + 1, sot + 101, sot + 105] if dims["n_vocab"] >= 51865 else [50257, 50362]
     max_new = args.new_tokens
 
-    # S independent batches in flight per GPU: the decode chain of ONE batch is latency-bound (258
-    # dependent launches per position), so consecutive steps (= independent batches) are software-
-    # pipelined over S contexts that share the weights and own a HIP stream + KV caches each.
-    import queue
-    import threading
+    # S independent decode groups in flight per GPU: the decode chain of ONE group is latency-bound, so
+    # consecutive steps (= independent batches) are software-pipelined over S contexts that share the weights and
+    # own a HIP stream + KV caches each.  The groups are formed by sharding.plan_groups -- a pure function of
+    # (steps, fuse, inflight), identical on every rank -- and the token streams are exchanged ONCE per run with a
+    # fixed-stride all-gather (sharding.run_grouped), so the collective never depends on which lane finished first.
     ctxs = [ctx] + [ctx.clone() for _ in range(S - 1)]
     gathered = None
     seen = []   # (steps in the group, tokens) of every finished group: compared after the timed region
 
     def run_steps(n_steps):
-        """n_steps batches of nb chunks, S in flight; returns summed stage ms of all steps."""
+        """n_steps batches of nb chunks as decode groups, S in flight; returns summed stage ms of all groups."""
         nonlocal gathered
-        todo = queue.Queue()
-        done = queue.Queue()
-        for i in range(n_steps):
-            todo.put(i)
         stage_sum = np.zeros(3)
         lock = threading.Lock()
+        plan = sharding.plan_groups(n_steps, F, S)
 
-        def worker(c):
-            while True:
-                k = 0
-                while k < F:                       # up to F consecutive steps form one decode group
-                    try:
-                        todo.get_nowait()
-                        k += 1
-                    except queue.Empty:
-                        break
-                if k == 0:
-                    return
-                toks, lens = c.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE,
-                                                 pcm_dtype=B.WM_I16, B=nb * k)
-                with lock:
-                    stage_sum[:] += c.last_stage_ms()
-                done.put((toks, lens, k))
+        def run_group(w, g, k):
+            c = ctxs[w]
+            toks, lens = c.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE,
+                                             pcm_dtype=B.WM_I16, B=nb * k)
+            with lock:
+                stage_sum[:] += c.last_stage_ms()
+                seen.append((k, toks))
+            return toks, lens
 
-        th = [threading.Thread(target=worker, args=(c,)) for c in ctxs]
-        for t in th:
-            t.start()
-        finished = 0
-        while finished < n_steps:
-            toks, lens, k = done.get()
-            finished += k
-            seen.append((k, toks))
-            if use_dist:
-                # the only exchange of the whole job: one fixed-stride all-gather of the token streams per group
-                gathered = sharding.gather_tokens(dist, toks, lens, nb * k * world, world, device="cuda")
-        for t in th:
-            t.join()
+        _, g = sharding.run_grouped(plan, S, run_group, nb, max_new, dist=dist if use_dist else None,
+                                    world_size=world, device="cuda" if use_dist else None)
+        if g is not None:
+            gathered = g
         return stage_sum
 
     def sync_all():

@@ -24,6 +24,9 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: exactly the functions declared here are exported. */
+#define WM_API __attribute__((visibility("default")))
+
 /* ------------------------------------------------------------------ status codes --- */
 enum {
     WM_OK = 0,
@@ -66,7 +69,7 @@ typedef struct wm_ctx wm_ctx;
  * kernels on device $WM_DEVICE (default 0).  Like the reference (unwrap -> panic ->
  * abort, lib.rs:45,85-87,106) it cannot report an error: on a HIP failure it prints the
  * reason to stderr and abort()s -- there is no CPU fallback. */
-void generate_spectrogram(double *audio, double *output);
+WM_API void generate_spectrogram(double *audio, double *output);
 
 /* Batched, typed, error-returning form of the same computation (lib.rs:49-102).
  *   pcm   : [n_chunks][480000] samples, dtype WM_I16 (x = s/32768), WM_F32 or WM_F64;
@@ -77,67 +80,67 @@ void generate_spectrogram(double *audio, double *output);
  *   out   : [n_chunks][n_mels][3000], dtype WM_F64 (f64 arithmetic end to end: the
  *           ABI-exact path) or WM_F32 (f32 arithmetic: the fast path); mem-space
  *           selectable (same `mem` as pcm). */
-int wm_logmel(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int n_chunks, int n_mels,
+WM_API int wm_logmel(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int n_chunks, int n_mels,
               void *out, wm_dtype out_dtype, wm_mem mem);
 
 /* --------------------------------------------------------- context / weight loading --- */
 
 /* Front-end-only context (no model): enough for wm_logmel. */
-int wm_create_frontend(int device, wm_ctx **out);
+WM_API int wm_create_frontend(int device, wm_ctx **out);
 
 /* Model context with uninitialised weights ( == Whisper.init, Whisper.swift:17-21, minus
  * the load).  Fill with wm_set_tensor / wm_load_weights / wm_init_synthetic, then
  * wm_finalize. */
-int wm_create(const wm_dims *dims, int device, wm_ctx **out);
+WM_API int wm_create(const wm_dims *dims, int device, wm_ctx **out);
 
 /* Set one parameter from host f32 data.  Names are openai-whisper state-dict keys, e.g.
  * "encoder.conv1.weight", "encoder.blocks.0.attn.query.weight",
  * "decoder.token_embedding.weight" (SURVEY.md 8f row 2).  n_elems must match. */
-int wm_set_tensor(wm_ctx *ctx, const char *name, const float *data, size_t n_elems);
+WM_API int wm_set_tensor(wm_ctx *ctx, const char *name, const float *data, size_t n_elems);
 /* Read a parameter back as f32 (the value the kernels use, i.e. after bf16 rounding for
  * matrix weights). */
-int wm_get_tensor(wm_ctx *ctx, const char *name, float *data, size_t n_elems);
+WM_API int wm_get_tensor(wm_ctx *ctx, const char *name, float *data, size_t n_elems);
 /* Flat weight file written by openai-whisper-coreml_amd/weights.py (format in DESIGN.md). */
-int wm_load_weights(wm_ctx *ctx, const char *path);
+WM_API int wm_load_weights(wm_ctx *ctx, const char *path);
 /* Deterministic synthetic weights generated ON DEVICE (hash-based, approx N(0, std^2));
  * identical values to weights.synthetic_state_dict(dims, seed) on the host. */
-int wm_init_synthetic(wm_ctx *ctx, uint64_t seed);
+WM_API int wm_init_synthetic(wm_ctx *ctx, uint64_t seed);
 /* Freeze weights: fuse QKV, permute conv taps, precompute tables.  Required before any
  * model call. */
-int wm_finalize(wm_ctx *ctx);
+WM_API int wm_finalize(wm_ctx *ctx);
 /* A second context on the same device that SHARES the (finalised, read-only) weights of `parent`
  * and owns its own HIP stream, activations, KV caches and decode graph.  Independent batches
  * submitted to different contexts from different host threads overlap on the GPU.  Destroy clones
  * before their parent. */
-int wm_clone(wm_ctx *parent, wm_ctx **out);
-void wm_destroy(wm_ctx *ctx);
+WM_API int wm_clone(wm_ctx *parent, wm_ctx **out);
+WM_API void wm_destroy(wm_ctx *ctx);
 
-const char *wm_last_error(void);
-int wm_get_dims(const wm_ctx *ctx, wm_dims *out);
+WM_API const char *wm_last_error(void);
+WM_API int wm_get_dims(const wm_ctx *ctx, wm_dims *out);
 
 /* ---------------------------------------------------------- boundary #2: the model --- */
 
 /* == encoderModel.prediction(x_1:).var_1385 (Whisper.swift:29; whisper_to_cml.py:10-23).
  *   mel: f32 [B][n_mels][3000]  ->  xa: f32 [B][n_audio_ctx][n_audio_state].
  * Both mem-space selectable (same `mem`). */
-int wm_encode(wm_ctx *ctx, const float *mel, int B, float *xa, wm_mem mem);
+WM_API int wm_encode(wm_ctx *ctx, const float *mel, int B, float *xa, wm_mem mem);
 
 /* == decoderModel.prediction(x_1:xa:).var_2217 (Whisper.swift:36; whisper_to_cml.py:25-43),
  * generalised from T == 1 to a T-token prefix (stateless: offset 0, no cache is kept).
  *   tokens: i32 [B][T];  xa: f32 [B][n_audio_ctx][d];  logits: f32 [B][T][n_vocab]. */
-int wm_decode_logits(wm_ctx *ctx, const int32_t *tokens, int B, int T, const float *xa,
+WM_API int wm_decode_logits(wm_ctx *ctx, const int32_t *tokens, int B, int T, const float *xa,
                      float *logits, wm_mem mem);
 
 /* == Whisper.decode (Whisper.swift:33-40): one decoder step on <|startoftranscript|>
  * (id `sot`, 50258 in the reference), arg-max over logits[lang_first .. lang_last]
  * (50259...50357 in the reference), FIRST maximal element wins (Swift max(by:)).
  *   lang_idx: i32 [B], index into Whisper.LANGUAGES. */
-int wm_detect_language(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first,
+WM_API int wm_detect_language(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first,
                        int32_t lang_last, int32_t *lang_idx, wm_mem mem);
 
 /* Same step, additionally returning the language probabilities of openai-whisper's detect_language() [3p]: softmax over
  * the language-token logits only.  probs: f32 [B][lang_last - lang_first + 1], same memory space as xa / lang_idx. */
-int wm_detect_language_probs(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first,
+WM_API int wm_detect_language_probs(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first,
                              int32_t lang_last, int32_t *lang_idx, float *probs, wm_mem mem);
 
 /* New surface asked for by BASELINE.json (not in the reference): front end + encoder +
@@ -150,7 +153,7 @@ int wm_detect_language_probs(wm_ctx *ctx, const float *xa, int B, int32_t sot, i
  *   eot        : stop token; pass -1 to suppress stopping (fixed-length benchmark decode);
  *   tokens_out : i32 [B][max_new] (host), padded with `eot` after a chunk stops;
  *   lens_out   : i32 [B] (host) generated length per chunk. */
-int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int B,
+WM_API int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int B,
                          const int32_t *prompt, int n_prompt, int max_new, int32_t eot,
                          int32_t *tokens_out, int32_t *lens_out, wm_mem mem);
 
@@ -160,7 +163,7 @@ int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int B
  *   suppress_first : n_first more ids excluded only for the FIRST generated token (SuppressBlank: " " and <|endoftext|>).
  * The lists are copied; n = n_first = 0 clears the filter.  wm_decode_logits / wm_detect_language are unaffected (raw
  * logits).  Contexts made later with wm_clone inherit the filter; existing clones must be set themselves. */
-int wm_set_suppress(wm_ctx *ctx, const int32_t *suppress, int n, const int32_t *suppress_first, int n_first);
+WM_API int wm_set_suppress(wm_ctx *ctx, const int32_t *suppress, int n, const int32_t *suppress_first, int n_first);
 
 /* openai-whisper's ApplyTimestampRules (whisper/decoding.py [3p]) for wm_transcribe_greedy, i.e. decoding WITH
  * timestamps (prompt without <|notimestamps|>): timestamps come in pairs, never decrease, the transcript opens with a
@@ -169,32 +172,32 @@ int wm_set_suppress(wm_ctx *ctx, const int32_t *suppress, int n, const int32_t *
  *   timestamp_begin : id of <|0.00|> (50364; 50365 for large-v3);  eot : <|endoftext|>.
  * Evaluated inside the fused logits / arg-max kernels; combine with wm_set_suppress (which should list <|notimestamps|>).
  * enable = 0 switches the rules off.  Same inheritance as wm_set_suppress. */
-int wm_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t timestamp_begin, int32_t eot,
+WM_API int wm_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t timestamp_begin, int32_t eot,
                            int32_t max_initial_timestamp_index);
 
 /* ------------------------------------------------------------ device memory helpers --- */
 /* For callers that keep inputs resident in HBM (bench.py; a Swift host would use them to
  * avoid the 5.7 MB/chunk PCIe round trip of the reference ABI). */
-int wm_dev_malloc(wm_ctx *ctx, size_t bytes, void **dptr);
-int wm_dev_free(wm_ctx *ctx, void *dptr);
-int wm_dev_upload(wm_ctx *ctx, void *dptr, const void *host, size_t bytes);
-int wm_dev_download(wm_ctx *ctx, void *host, const void *dptr, size_t bytes);
-int wm_sync(wm_ctx *ctx);
+WM_API int wm_dev_malloc(wm_ctx *ctx, size_t bytes, void **dptr);
+WM_API int wm_dev_free(wm_ctx *ctx, void *dptr);
+WM_API int wm_dev_upload(wm_ctx *ctx, void *dptr, const void *host, size_t bytes);
+WM_API int wm_dev_download(wm_ctx *ctx, void *host, const void *dptr, size_t bytes);
+WM_API int wm_sync(wm_ctx *ctx);
 
 /* -------------------------------------------------------------------- measurement --- */
 /* Per-kernel-family HIP-event timing on the context's stream.  When enabled, every launch
  * of a profiled kernel family is bracketed by hipEventRecord on the launch stream; the
  * totals are read back with wm_profile_get (which synchronises). */
-int wm_profile_enable(wm_ctx *ctx, int on);
-int wm_profile_reset(wm_ctx *ctx);
+WM_API int wm_profile_enable(wm_ctx *ctx, int on);
+WM_API int wm_profile_reset(wm_ctx *ctx);
 /* Bias (microseconds) of an event-bracketed launch on this stream, calibrated with a kernel that spins
  * for a known time of the device clock: subtract it from a family's mean launch duration. */
-int wm_profile_overhead_us(wm_ctx *ctx, float *us);
+WM_API int wm_profile_overhead_us(wm_ctx *ctx, float *us);
 /* Writes a JSON object {"family": {"ms": total_ms, "n": launches}, ...} into buf. */
-int wm_profile_json(wm_ctx *ctx, char *buf, size_t buf_bytes);
+WM_API int wm_profile_json(wm_ctx *ctx, char *buf, size_t buf_bytes);
 /* Wall-clock stage split of the last wm_transcribe_greedy call, in ms (HIP events):
  * [0] front end, [1] encoder + cross-KV projection, [2] decode loop. */
-int wm_last_stage_ms(wm_ctx *ctx, float out3[3]);
+WM_API int wm_last_stage_ms(wm_ctx *ctx, float out3[3]);
 
 #ifdef __cplusplus
 }

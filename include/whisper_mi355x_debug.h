@@ -1,5 +1,6 @@
 /*
- * whisper_mi355x_debug.h -- test hooks exported by libwhisper_mi355x.so.
+ * whisper_mi355x_debug.h -- test hooks exported by libwhisper_mi355x_dbg.so (the product library,
+ * libwhisper_mi355x.so, does not contain them).
  *
  * NOT part of the drop-in surface: these let tests/ drive individual HIP kernels (and a
  * few host-side helpers) through the same C ABI conventions, so each kernel can be
@@ -17,51 +18,51 @@ extern "C" {
 
 /* Host-only: slaney mel filterbank as librosa.filters.mel(sr=16000, n_fft=400, n_mels)
  * builds it (the recipe behind export_m80.py:4's mel_filters.npz); out: [n_mels][201]. */
-int wmdbg_mel_filterbank(int n_mels, float *out);
+WM_API int wmdbg_mel_filterbank(int n_mels, float *out);
 /* Host-only: the embedded copy of the reference's m80.npy (80*201 f32). */
-int wmdbg_mel80(float *out);
+WM_API int wmdbg_mel80(float *out);
 
 /* ---- single-kernel hooks (GPU).  Matrices are given as f32 and rounded to bf16 inside,
  * exactly as the weights / activations are held in HBM. ---------------------------------- */
 /* C[M][N] = A[M][K] . W[N][K]^T (+bias); epi: 6 = f32 out, 0 = bf16 out, 1 = gelu -> bf16,
  * 2 = C += (f32 residual).  K % 64 == 0.  C is f32 on the host in every case. */
-int wmdbg_gemm(wm_ctx *ctx, const float *A, const float *W, const float *bias, float *C, int M, int N,
+WM_API int wmdbg_gemm(wm_ctx *ctx, const float *A, const float *W, const float *bias, float *C, int M, int N,
                int K, int epi);
 /* LayerNorm over the last axis (eps 1e-5): f32 result and the bf16 result widened to f32. */
-int wmdbg_layernorm(wm_ctx *ctx, const float *x, const float *g, const float *b, int rows, int d,
+WM_API int wmdbg_layernorm(wm_ctx *ctx, const float *x, const float *g, const float *b, int rows, int d,
                     float *out_f32, float *out_bf16_as_f32);
 /* Non-causal MHA, head_dim 64: q,k,v,out f32 [B][S][H*64]. */
-int wmdbg_enc_attention(wm_ctx *ctx, const float *q, const float *k, const float *v, int B, int H, int S,
+WM_API int wmdbg_enc_attention(wm_ctx *ctx, const float *q, const float *k, const float *v, int B, int H, int S,
                         float *out);
 /* Decode-step skinny GEMM: out[B][N] = (ln_g ? LayerNorm(x) : x) . W[N][K]^T + bias; B <= 16. */
-int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, const float *ln_b, const float *W,
+WM_API int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, const float *ln_b, const float *W,
                    const float *bias, float *out, int B, int N, int K);
 /* Single-query attention over a cache: q [B][H*64], k/v [B][H][T][64], keys 0..n_keys-1;
  * out = the bf16 head outputs widened to f32.  nsplit in 1..8. */
-int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, const float *v, int B, int H, int T,
+WM_API int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, const float *v, int B, int H, int T,
                         int n_keys, int nsplit, float *out);
 
 /* ---- micro-benchmarks: average microseconds per launch over `iters` back-to-back launches
  * that cycle over n_mats weight matrices / n_slices cache slices (defeats L2 / MALL reuse). */
-int wmdbg_bench_dec_gemv(wm_ctx *ctx, int B, int N, int K, int ln, int resid, int n_mats, int iters,
+WM_API int wmdbg_bench_dec_gemv(wm_ctx *ctx, int B, int N, int K, int ln, int resid, int n_mats, int iters,
                          int nw_override, float *avg_us);
-int wmdbg_bench_dec_attention(wm_ctx *ctx, int B, int H, int T, int n_keys, int nsplit, int n_slices,
+WM_API int wmdbg_bench_dec_attention(wm_ctx *ctx, int B, int H, int T, int n_keys, int nsplit, int n_slices,
                               int iters, float *avg_us);
 
 /* Dependent-launch floor: average microseconds per trivial kernel, eager vs hipGraph replay. */
-int wmdbg_bench_launch_floor(wm_ctx *ctx, int iters, int grid, float *eager_us, float *graph_us);
+WM_API int wmdbg_bench_launch_floor(wm_ctx *ctx, int iters, int grid, float *eager_us, float *graph_us);
 
 /* Wall time (us) of one replay of a captured graph with ONE chain of `iters` spinning kernels vs TWO
  * independent chains: tells whether hipGraph runs parallel branches concurrently on this runtime. */
-int wmdbg_bench_graph_branches(wm_ctx *ctx, int iters, int grid, int us_each, float *one_us, float *two_us);
+WM_API int wmdbg_bench_graph_branches(wm_ctx *ctx, int iters, int grid, int us_each, float *one_us, float *two_us);
 
 /* Mean duration (us) of one encoder GEMM launch, C[M][N] = A[M][K] W[N][K]^T, back to back, on encoder-like operands
  * (A ~ N(0,1), W ~ N(0,0.02^2)); launches rotate over n_w copies of W (n_w large: W streams from HBM as in the model). */
-int wmdbg_bench_gemm(wm_ctx *ctx, int M, int N, int K, int epi, int iters, int n_w, float *us);
+WM_API int wmdbg_bench_gemm(wm_ctx *ctx, int M, int N, int K, int epi, int iters, int n_w, float *us);
 
 /* Force the encoder GEMM tile: 128 (128 x 128, 4 waves), 256 (256 x 256, 8 waves, staggered phases) or 0 = automatic.
  * Process-wide; used by the parity tests and A/B probes to run every shape through both kernels. */
-int wmdbg_set_gemm_tile(int tile);
+WM_API int wmdbg_set_gemm_tile(int tile);
 
 #ifdef __cplusplus
 }

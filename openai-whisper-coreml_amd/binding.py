@@ -20,6 +20,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libwhisper_mi355x.so")
+# the product objects + the wmdbg_* kernel test hooks (include/whisper_mi355x_debug.h): tests / tools only
+DEBUG_LIB_PATH = os.path.join(HERE, "libwhisper_mi355x_dbg.so")
 
 WM_OK = 0
 WM_I16, WM_F32, WM_F64, WM_BF16 = 0, 1, 2, 3
@@ -65,6 +67,15 @@ MODEL_DIMS = {
 }
 
 _lib = None
+_dbg_lib = None
+
+
+def load_debug_library():
+    """dlopen libwhisper_mi355x_dbg.so: the same objects as the product plus the wmdbg_* hooks."""
+    global _dbg_lib
+    if _dbg_lib is None:
+        _dbg_lib = load_library(DEBUG_LIB_PATH)
+    return _dbg_lib
 
 
 def load_library(path=None):
@@ -149,8 +160,8 @@ def generateSpectrogram(audio):
 class Context:
     """Thin RAII wrapper over wm_ctx (front end only unless `dims` is given)."""
 
-    def __init__(self, dims=None, device=0):
-        self.lib = load_library()
+    def __init__(self, dims=None, device=0, debug=False):
+        self.lib = load_debug_library() if debug else load_library()
         self.handle = ctypes.c_void_p()
         if dims is None:
             _check(self.lib, self.lib.wm_create_frontend(int(device), ctypes.byref(self.handle)))

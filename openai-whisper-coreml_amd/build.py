@@ -15,10 +15,13 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libwhisper_mi355x.so")
+DBG_LIB = os.path.join(HERE, "libwhisper_mi355x_dbg.so")   # product objects + csrc/debug_hooks.cpp (tests / tools only)
+DEBUG_ONLY = ("debug_hooks.cpp",)
 HOST_BIN = os.path.join(HERE, "host", "lid_main")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-fvisibility=hidden",   # only the WM_API functions of include/*.h are exported
          "-I", os.path.join(ROOT, "include")]
 
 
@@ -57,16 +60,28 @@ def build(force=False, verbose=True):
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         res = list(ex.map(lambda s: _compile(s, force, hdr_t), srcs))
     objs = [o for o, _ in res]
-    if any(c for _, c in res) or not os.path.exists(LIB) or force:
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [
-            "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-        if verbose:
-            print("built", LIB)
-    elif verbose:
-        print("up to date:", LIB)
+    prod = [o for o, s_ in zip(objs, srcs) if s_ not in DEBUG_ONLY]
+    changed = any(c for _, c in res) or force
+    # linker version scripts: the product exports the C ABI of include/whisper_mi355x.h and nothing else (no libstdc++
+    # template instantiations, no __hip_cuid_*); the debug library additionally exports the wmdbg_* hooks
+    maps = {}
+    for name, pats in (("product", ["generate_spectrogram", "wm_*"]), ("debug", ["generate_spectrogram", "wm_*", "wmdbg_*"])):
+        maps[name] = os.path.join(OBJ, "exports_%s.map" % name)
+        text = "{\n  global:\n%s  local: *;\n};\n" % "".join("    %s;\n" % p_ for p_ in pats)
+        if not os.path.exists(maps[name]) or open(maps[name]).read() != text:
+            with open(maps[name], "w") as f:
+                f.write(text)
+    for lib, members, vmap in ((LIB, prod, maps["product"]), (DBG_LIB, objs, maps["debug"])):
+        if changed or not os.path.exists(lib):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + members + [
+                "-Wl,-rpath,/opt/rocm/lib", "-Wl,--version-script=" + vmap, "-lpthread"]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+            if verbose:
+                print("built", lib)
+        elif verbose:
+            print("up to date:", lib)
     return LIB
 
 

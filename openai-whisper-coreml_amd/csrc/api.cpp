@@ -328,18 +328,3 @@ extern "C" void generate_spectrogram(double *audio, double *output) {
         abort();
     }
 }
-
-// ---------------------------------------------------------------- host-only test hooks
-#include "../../include/whisper_mi355x_debug.h"
-extern "C" int wmdbg_mel_filterbank(int n_mels, float *out) {
-    WM_REQUIRE(out && n_mels > 0 && n_mels <= 256, WM_ERR_INVALID, "bad args");
-    std::vector<float> f;
-    wm_mel_filterbank(n_mels, f);
-    memcpy(out, f.data(), f.size() * sizeof(float));
-    return WM_OK;
-}
-extern "C" int wmdbg_mel80(float *out) {
-    WM_REQUIRE(out, WM_ERR_INVALID, "null");
-    memcpy(out, wm_mel80_table(), sizeof(float) * 80 * 201);
-    return WM_OK;
-}

@@ -52,15 +52,15 @@ __device__ __forceinline__ unsigned long long argmax_key(float v, int n) {
 }
 
 struct DecGemvDev {
-    int B, N, K, KC;
-    const bf16_t *W;
-    const float *bias;
-    const float *x, *ln_g, *ln_b;
-    const float *stats_in;  // DA_LN: [stats_parts][16][2] partial (sum x, sum x^2) per row
+    int B, N, K;
+    const bf16_t *W;        // WL_TILED [N padded to 16][K]; LayerNorm modes: gamma folded in (W_nk * g_k, rounded to bf16)
+    const float *c1;        // LayerNorm fold: c1[n] = sum_k W'_nk (the folded, rounded weights); plain modes: unused
+    const float *c2;        // bias[n] (+ sum_k beta_k W_nk in LayerNorm modes); may be null
+    const bf16_t *a;        // [B][K] bf16 activations: bf16 copy of the residual, attention output or GELU output
+    const float *stats_in;  // LayerNorm: [blk][stats_parts][16][2] partial (sum x, sum x^2) per row of the f32 residual
     int stats_parts;
     long stats_stride;      // floats between the statistics of consecutive 16-row batch blocks
     float *stats_out;       // DE_RESID: this launch's per-tile partials of the UPDATED residual
-    const bf16_t *a_bf16;
     float *out_f32;
     bf16_t *out_bf16;
     bf16_t *kcache, *vcache;
@@ -68,14 +68,15 @@ struct DecGemvDev {
     int n_ctx, n_head;
     long ldo;
     unsigned long long *tilemax;  // [B][n_tiles] (DE_LOGITS)
-    int n_tiles, n_tiles_pad;  // n_tiles_pad: n_tiles rounded up to 8 when the batch has more than one 16-row block
+    int n_tiles, n_tiles_pad;     // n_tiles_pad: n_tiles rounded up to 8 when a tile is shared by several workgroups
     int arg_first, arg_last;
     const unsigned *mask;  // DE_LOGITS: suppressed-token bitmaps [2][mask_words] or null
     int mask_words, mask_first_pos;
     WmTsDev ts;            // DE_LOGITS: timestamp rules (ts.rng == null: off)
-    const char *pf_ptr;   // next GEMV's weights: extra workgroups pull them into this XCD's L2
-    long pf_tile_bytes;  // bytes of one 16-row weight tile of that matrix
+    const char *pf_ptr;    // next GEMV's weights: extra workgroups pull them into this XCD's L2
+    long pf_tile_bytes;    // bytes of one 16-row weight tile of that matrix
     int pf_tiles;
+    int bgroups;           // workgroups per weight tile: group g takes the 16-row batch blocks g, g + bgroups, ...
 };
 
 // L2 warm-up workgroup: blockIdx >= n_tiles of the compute grid.  Workgroup n_tiles + t reads tile t of
@@ -98,156 +99,133 @@ __device__ __forceinline__ void l2_warm_tile(const char *base, long tile_bytes, 
     }
 }
 
-// Weight stream of one wave: WG_MAX k-steps are issued up front, unconditionally (steps past
-// the wave's range re-read its last fragment: an L1 hit, no HBM traffic), BEFORE the LayerNorm
-// prologue, so the HBM latency of the weights overlaps the statistics.  A fragments come from
-// the wave-private LDS image built by the prologue, or straight from a bf16 activation row in
-// L2 -- always unconditional loads from a clamped row: a lane-divergent branch around a load
-// makes hipcc serialise it behind s_waitcnt vmcnt(0) (measured: 10 dependent L2 round trips
-// per wave, ~10 us per launch).
-constexpr int WG_MAX = 12;
-
-// LDS carve (dynamic): red [NW][64][4] f32 | part [2][NW][16] f32 | xs [NW][B][KC+8] bf16 (DA_LN)
-template <int AMODE, int EPI, int NW>
-__global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
+// The decode GEMV (round 2): out[b][n] = sum_k a[b][k] W[n][k] for a decode group of any size.
+//   * one workgroup per 16-row weight tile; its NW waves split K (SPW k-steps of 32 each -- the split depends on K
+//     only, never on the batch, so a row's sum is formed in the same order whatever group it is decoded in);
+//   * every weight load is issued first (10-40 KiB per workgroup in flight), then the activation fragments of the
+//     first batch block: bf16 rows straight from L2 in MFMA A-operand order -- no LDS staging, no prologue;
+//   * LayerNorm is FOLDED: gamma lives in the weights (W' = W g), so the product runs on the raw bf16 residual and the
+//     row statistics enter in the epilogue, out = rstd (a W'^T - mean c1) + c2 -- they arrive as deterministic per-tile
+//     partial sums of the f32 residual from whoever wrote it last and are off the critical path;
+//   * batches above 16 rows: blocks of 16 looped INSIDE the workgroup with the weights held in registers and the next
+//     block's fragments requested before this block's reduction (bgroups workgroups share a tile at large batches);
+//   * cross-wave (split-K) sums through a double-buffered LDS slab in wave order, one barrier per block; wave 0 runs the
+//     fused epilogue: bias / GELU / residual (+ bf16 copy + partial statistics) / KV append / arg-max (+ suppress
+//     bitmaps, timestamp rules).
+// LDS carve (dynamic): red [2][NW][64][4] f32 | st [16][2] f32
+template <int SPW, int EPI, bool LN>
+__global__ __launch_bounds__(LN || SPW == 12 ? 512 : 1024) void dec_gemv_kernel(DecGemvDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // Batches above 16 run as nblk blocks of 16 rows (the MFMA's M) on the same weight tile.  Workgroup id ->
-    // (tile, block): ids 8g .. 8g+7 are tiles 8(g / nblk) .. +7 of block g % nblk, so the blocks of a tile are
-    // dispatched back to back AND on the same XCD (id % 8): the later blocks' weight reads hit the L2 the first one
-    // filled -- one HBM stream for all rows.  (nblk == 1: id == tile.)
-    const int nblk = (p.B + 15) >> 4;
+    const int NW = blockDim.x >> 6;
+    // Workgroup id -> (tile, group): ids 8q .. 8q+7 are tiles 8(q / G) .. +7 of group q % G, so the workgroups of a tile
+    // are dispatched back to back AND on the same XCD (id % 8): the later ones read the weights from the L2 the first
+    // one filled -- one HBM stream per tile.  (G == 1: id == tile.)
+    const int G = p.bgroups;
     const int wg = blockIdx.x;
-    const int grp = wg >> 3;
-    const int tile = (grp / nblk) * 8 + (wg & 7);
-    const int blk = grp % nblk;
-    if (wg >= p.n_tiles_pad * nblk || tile >= p.n_tiles) {  // workgroup-uniform: warm-up workgroups and row padding
-        const int t = wg - p.n_tiles_pad * nblk;
+    const int q = wg >> 3;
+    const int tile = (q / G) * 8 + (wg & 7);
+    const int grp = q % G;
+    if (wg >= p.n_tiles_pad * G || tile >= p.n_tiles) {  // workgroup-uniform: warm-up workgroups and row padding
+        const int t = wg - p.n_tiles_pad * G;
         if (t >= 0 && t < p.pf_tiles) l2_warm_tile(p.pf_ptr, p.pf_tile_bytes, t, NW * 64);
         return;
     }
-    if (blk != 0) {  // workgroup-uniform: rebase every per-row pointer of the by-value argument block
-        const long r0 = (long)blk * 16;
-        if (p.x) p.x += r0 * p.K;
-        if (p.a_bf16) p.a_bf16 += r0 * p.K;
-        if (p.out_f32) p.out_f32 += r0 * (EPI == DE_QKV ? (long)(p.N / 3) : p.ldo);
-        if (p.out_bf16) p.out_bf16 += r0 * p.ldo;
-        if (p.kcache) p.kcache += r0 * p.n_head * p.n_ctx * 64;
-        if (p.vcache) p.vcache += r0 * p.n_head * p.n_ctx * 64;
-        if (p.stats_in) p.stats_in += (long)blk * p.stats_stride;
-        if (p.stats_out) p.stats_out += (long)blk * p.stats_stride;
-        if (p.tilemax) p.tilemax += r0 * p.n_tiles;
-        if (p.ts.rng) {
-            p.ts.rng += r0 * 4;
-            p.ts.key_ts += r0 * p.n_tiles;
-            p.ts.lse += r0 * p.n_tiles * 2;
-        }
-        p.B -= (int)r0;
-    }
-    if (p.B > 16) p.B = 16;
     float *red = (float *)smem;
-    float *part = red + NW * 256;
-    char *xs_all = (char *)(part + 2 * NW * 16);
+    float *st = red + 2 * NW * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrow = lane & 15, kq = lane >> 4;
     const int n0 = tile * 16;
-    const int kbase = wave * p.KC;
-    const int nsteps = p.KC >> 5;
     // fragment-tiled weights (WL_TILED): k-step s of n-tile t is the contiguous KiB at
     // ((t * K/32 + s) * 64 + lane) * 8 -- one perfectly coalesced dwordx4 per lane per step
-    const bf16_t *wp = p.W + (((long)tile * (p.K >> 5) + (long)wave * nsteps) * 64 + lane) * 8;
-    const bool live = nrow < p.B;
-    const int rowc = live ? nrow : p.B - 1;  // clamped batch row for unconditional loads
-    const int xs_stride = (p.KC + 8) * 2;    // bytes; the 16 B pad keeps ds_read_b128 conflict-free
-    char *xs = xs_all + (long)wave * p.B * xs_stride;
-
-    // ---- 1. weight stream in flight first ---------------------------------------------------
-    u32x4 wf[WG_MAX];
+    const bf16_t *wp = p.W + (((long)tile * (p.K >> 5) + (long)wave * SPW) * 64 + lane) * 8;
+    u32x4 wf[SPW];
 #pragma unroll
-    for (int u = 0; u < WG_MAX; ++u) {
-        const int sc = u < nsteps ? u : nsteps - 1;
-        wf[u] = __builtin_nontemporal_load((const u32x4 *)(wp + sc * 512));
+    for (int u = 0; u < SPW; ++u) wf[u] = __builtin_nontemporal_load((const u32x4 *)(wp + u * 512));
+    const int kbase = wave * SPW * 32 + kq * 8;
+    u32x4 af[SPW];
+    int b0 = grp * 16;
+    {
+        const int rb = b0 + nrow;
+        const bf16_t *ap = p.a + (long)(rb < p.B ? rb : p.B - 1) * p.K + kbase;  // clamped row: unconditional loads
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) af[u] = *(const u32x4 *)(ap + u * 32);
     }
-
-    // ---- 1b. epilogue operands of wave 0 (bias, old residual, position): requested now so the
-    // kernel has ONE global-memory round trip on its critical path, not one per phase
+    // epilogue operands of wave 0 that do not depend on the batch block
     const int n = n0 + nrow;
     const bool nvalid = n < p.N;
     const int nc = nvalid ? n : p.N - 1;
-    float bvs = 0.f, xold[4] = {0.f, 0.f, 0.f, 0.f};
+    float c1v = 0.f, c2v = 0.f;
     int pos = 0;
     unsigned mword0 = 0u, mword1 = 0u;
-    int4 trng[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) trng[r] = make_int4(0, 0, 0, 0);
     if (wave == 0) {  // wave-uniform
-        if (p.bias) bvs = p.bias[nc];
+        if (p.c2) c2v = p.c2[nc];
+        if (LN) c1v = p.c1[nc];
         if (p.pos_ptr) pos = *p.pos_ptr;
         if (EPI == DE_LOGITS && p.mask) {
             mword0 = p.mask[nc >> 5];
             mword1 = p.mask[p.mask_words + (nc >> 5)];
         }
-        if (EPI == DE_LOGITS && p.ts.rng) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int b = kq * 4 + r;
-                trng[r] = *(const int4 *)(p.ts.rng + (b < p.B ? b : p.B - 1) * 4);
-            }
-        }
-        if (EPI == DE_RESID) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int b = kq * 4 + r;
-                xold[r] = p.out_f32[(long)(b < p.B ? b : p.B - 1) * p.ldo + nc];
-            }
-        }
     }
-
-    if (AMODE == DA_LN) {
-        // ---- 2. fused LayerNorm apply: this wave normalises x[0..B)[kbase .. kbase+KC) into its
-        // private LDS tile.  The row statistics were produced by whoever wrote x last (embedding
-        // or a DE_RESID launch) as per-tile partial sums in a FIXED slab order, so summing them
-        // here is deterministic and needs no workgroup barrier or atomics.  Every load of this
-        // prologue (statistics, gamma/beta, 8 activation rows) is issued before the first use.
-        float *st = part + wave * 32;  // [16][2] mean, rstd (wave-private)
-        const int row = lane & 15, grp = lane >> 4;  // 4 lane groups stride over the parts
-        constexpr int SP = 20;                       // parts per lane group: d/16 <= 80 parts
-        float2 sv[SP];
+    int par = 0;
+    for (; b0 < p.B; b0 += G * 16, par ^= 1) {  // workgroup-uniform trip count
+        const int nb = p.B - b0 < 16 ? p.B - b0 : 16;  // rows of this block
+        // ---- wave 0: this block's epilogue operands, requested before the products
+        float xold[4] = {0.f, 0.f, 0.f, 0.f};
+        int4 trng[4];
 #pragma unroll
-        for (int u = 0; u < SP; ++u) {
-            const int pc = grp + 4 * u < p.stats_parts ? grp + 4 * u : 0;  // clamped, masked below
-            sv[u] = *(const float2 *)(p.stats_in + ((long)pc * 16 + row) * 2);
-        }
-        const int kc4 = p.KC >> 2;
-        int j4c[2];
+        for (int r = 0; r < 4; ++r) trng[r] = make_int4(0, 0, 0, 0);
+        constexpr int SP = 20;  // statistics parts per lane group: d/16 <= 80 parts
+        float2 sv[LN ? SP : 1];
+        if (wave == 0) {
+            if (EPI == DE_RESID) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) j4c[u] = lane + 64 * u < kc4 ? lane + 64 * u : kc4 - 1;
-        float4 gv[2], bv[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            gv[u] = *(const float4 *)(p.ln_g + kbase + 4 * j4c[u]);
-            bv[u] = *(const float4 *)(p.ln_b + kbase + 4 * j4c[u]);
-        }
-        // activation rows travel in groups of four through two register buffers: rows 0-3 and 4-7 are requested
-        // here, each later group as soon as the buffer it reuses has been consumed (64 VGPRs at any batch size;
-        // holding all 16 rows cost 128 and a third of the resident workgroups)
-        float4 xa[4][2], xb[4][2];
-        auto fetch = [&](float4 (&xr)[4][2], int b0) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int bc = b0 + b < p.B ? b0 + b : p.B - 1;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) xr[b][u] = *(const float4 *)(p.x + (long)bc * p.K + kbase + 4 * j4c[u]);
+                for (int r = 0; r < 4; ++r) {
+                    const int bl = kq * 4 + r;
+                    xold[r] = p.out_f32[(long)(b0 + (bl < nb ? bl : nb - 1)) * p.ldo + nc];
+                }
             }
-        };
-        fetch(xa, 0);
-        fetch(xb, 4);
-        {
+            if (EPI == DE_LOGITS && p.ts.rng) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int bl = kq * 4 + r;
+                    trng[r] = *(const int4 *)(p.ts.rng + (long)(b0 + (bl < nb ? bl : nb - 1)) * 4);
+                }
+            }
+            if (LN) {
+                // all K/16 parts of the block are valid (the embedding kernels zero the ones they do not write), K/16 is
+                // a multiple of 4: every lane group reads K/64 of them, a wave-uniform count
+                const float *sp = p.stats_in + (long)(b0 >> 4) * p.stats_stride + (kq * 16 + nrow) * 2;
+                const int nu = p.K >> 6;
+#pragma unroll
+                for (int u = 0; u < SP; ++u) {
+                    sv[u] = make_float2(0.f, 0.f);
+                    if (u < nu) sv[u] = *(const float2 *)(sp + u * 128);
+                }
+            }
+        }
+        // ---- products of this wave's K range
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < SPW; ++u)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[u]),
+                                                          __builtin_bit_cast(bf16x8, wf[u]), acc, 0, 0, 0);
+        // ---- next block's fragments: in flight during the reduction and the epilogue
+        if (b0 + G * 16 < p.B) {
+            const int rb = b0 + G * 16 + nrow;
+            const bf16_t *ap = p.a + (long)(rb < p.B ? rb : p.B - 1) * p.K + kbase;
+#pragma unroll
+            for (int u = 0; u < SPW; ++u) af[u] = *(const u32x4 *)(ap + u * 32);
+        }
+        float *redp = red + par * NW * 256;
+        if (wave != 0) *(f32x4 *)(redp + (wave * 64 + lane) * 4) = acc;
+        if (LN && wave == 0) {
+            // row statistics: the partial sums were written in a FIXED slab order by the producer of the residual, so
+            // this sum is deterministic and needs no atomics; every lane ends with (rstd, -mean rstd) of row lane & 15
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int u = 0; u < SP; ++u) {
-                const float m = grp + 4 * u < p.stats_parts ? 1.f : 0.f;
-                s1 += sv[u].x * m;
-                s2 += sv[u].y * m;
+                s1 += sv[u].x;
+                s2 += sv[u].y;
             }
             s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
             s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
@@ -255,167 +233,137 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
             float var = s2 / (float)p.K - mean * mean;
             var = var > 0.f ? var : 0.f;
             const float rstd = rsqrtf(var + 1e-5f);
-            if (lane < 16) *(float2 *)(st + lane * 2) = make_float2(rstd, -mean * rstd);  // y = x*rstd - mean*rstd
+            if (lane < 16) *(float2 *)(st + lane * 2) = make_float2(rstd, -mean * rstd);
         }
-        // normalise: t = x*rstd + (-mean*rstd), y = t*g + b, as packed f32 FMAs; bf16 pairs by v_cvt_pk_bf16_f32
-        auto apply = [&](const float4 (&xr)[4][2], int b0) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int br = b0 + b < p.B ? b0 + b : p.B - 1;  // duplicates rewrite row B-1 with equal data
-                const float2 ms = *(const float2 *)(st + br * 2);
-                const f32x2 a2 = {ms.x, ms.x}, c2 = {ms.y, ms.y};
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const f32x2 x01 = {xr[b][u].x, xr[b][u].y}, x23 = {xr[b][u].z, xr[b][u].w};
-                    const f32x2 g01 = {gv[u].x, gv[u].y}, g23 = {gv[u].z, gv[u].w};
-                    const f32x2 b01 = {bv[u].x, bv[u].y}, b23 = {bv[u].z, bv[u].w};
-                    const f32x2 y01 = __builtin_elementwise_fma(__builtin_elementwise_fma(x01, a2, c2), g01, b01);
-                    const f32x2 y23 = __builtin_elementwise_fma(__builtin_elementwise_fma(x23, a2, c2), g23, b23);
-                    const unsigned lo = __builtin_bit_cast(unsigned, __builtin_convertvector(y01, bf16x2));
-                    const unsigned hi = __builtin_bit_cast(unsigned, __builtin_convertvector(y23, bf16x2));
-                    // clamped column: lanes past the chunk rewrite column kc4-1 with equal data
-                    *(uint2 *)(xs + br * xs_stride + j4c[u] * 8) = make_uint2(lo, hi);
-                }
-            }
-        };
-        apply(xa, 0);
-        if (p.B > 8) fetch(xa, 8);    // wave-uniform branches: scalar, no divergence around the loads
-        if (p.B > 4) apply(xb, 4);
-        if (p.B > 12) fetch(xb, 12);
-        if (p.B > 8) apply(xa, 8);
-        if (p.B > 12) apply(xb, 12);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    // ---- 3. A fragments + MFMA ---------------------------------------------------------------
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const char *xs_row = xs + rowc * xs_stride;
-    const bf16_t *a_row = (AMODE == DA_BF16) ? p.a_bf16 + (long)rowc * p.K + kbase : nullptr;
-    u32x4 af[WG_MAX];
-#pragma unroll
-    for (int u = 0; u < WG_MAX; ++u) {
-        const int sc = u < nsteps ? u : nsteps - 1;
-        if (AMODE == DA_LN)
-            af[u] = *(const u32x4 *)(xs_row + (sc * 32 + kq * 8) * 2);
-        else
-            af[u] = *(const u32x4 *)(a_row + sc * 32 + kq * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < WG_MAX; ++u) {
-        u32x4 av = af[u];
-        if (!live || u >= nsteps) av = (u32x4){0u, 0u, 0u, 0u};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av),
-                                                      __builtin_bit_cast(bf16x8, wf[u]), acc, 0, 0, 0);
-    }
-    // generic tail (KC > 384): two steps at a time
-    for (int s0 = WG_MAX; s0 < nsteps; s0 += 2) {
-        u32x4 w2[2], a2[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int sc = s0 + u < nsteps ? s0 + u : nsteps - 1;
-            w2[u] = __builtin_nontemporal_load((const u32x4 *)(wp + sc * 512));
-            a2[u] = (AMODE == DA_LN) ? *(const u32x4 *)(xs_row + (sc * 32 + kq * 8) * 2)
-                                     : *(const u32x4 *)(a_row + sc * 32 + kq * 8);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            u32x4 av = a2[u];
-            if (!live || s0 + u >= nsteps) av = (u32x4){0u, 0u, 0u, 0u};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av),
-                                                          __builtin_bit_cast(bf16x8, w2[u]), acc, 0, 0, 0);
-        }
-    }
-
-    // ---- cross-wave (split-K) reduction through LDS ----------------------------------------
-    if (NW > 1) {
-        *(f32x4 *)(red + (wave * 64 + lane) * 4) = acc;
         __syncthreads();
-        if (wave != 0) return;
-#pragma unroll
-        for (int w = 1; w < NW; ++w) acc += *(const f32x4 *)(red + (w * 64 + lane) * 4);
-    }
+        if (wave != 0) continue;  // waves 1.. go on to the next block; the LDS slab alternates
+        for (int w = 1; w < NW; ++w) acc += *(const f32x4 *)(redp + (w * 64 + lane) * 4);
 
-    // ---- epilogue (wave 0): D col n = lane & 15, rows b = kq*4 + r --------------------------
+        // ---- epilogue (wave 0): D col n = lane & 15, rows b = b0 + kq*4 + r -------------------
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int b = kq * 4 + r;
-        const float v = acc[r] + bvs;
-        if (EPI == DE_LOGITS && p.ts.rng) {
-            // timestamp rules: best allowed text token, best allowed timestamp, and the (max, sum exp) partial of the
-            // allowed timestamps of this tile (only tiles that reach into the timestamp range carry the last two)
-            const unsigned mw = (pos == p.mask_first_pos) ? mword1 : mword0;
-            const bool ok = b < p.B && nvalid && !((mw >> (n & 31)) & 1u);
-            const bool in_text = ok && n >= trng[r].x && n < trng[r].y;
-            const bool in_ts = ok && n >= trng[r].z && n < trng[r].w;
-            unsigned long long kt = in_text ? argmax_key(v, n) : 0ull, ks = in_ts ? argmax_key(v, n) : 0ull;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                const unsigned long long a = __shfl_xor(kt, o), c = __shfl_xor(ks, o);
-                kt = a > kt ? a : kt;
-                ks = c > ks ? c : ks;
-            }
-            if (b < p.B && nrow == 0) p.tilemax[(long)b * p.n_tiles + tile] = kt;
-            if (n0 + 16 > p.ts.ts_begin) {  // workgroup-uniform
-                float mx = in_ts ? v : -1e30f;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-                float se = in_ts ? __expf(v - mx) : 0.f;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o);
-                if (b < p.B && nrow == 0) {
-                    p.ts.key_ts[(long)b * p.n_tiles + tile] = ks;
-                    *(float2 *)(p.ts.lse + ((long)b * p.n_tiles + tile) * 2) = make_float2(mx, se);
-                }
-            }
-            if (b < p.B && nvalid && p.out_f32) p.out_f32[(long)b * p.ldo + n] = v;
-            continue;
-        }
-        if (EPI == DE_LOGITS) {
-            // arg-max over [arg_first, arg_last], first maximal index wins (Whisper.swift:38)
-            unsigned long long key = 0ull;
-            const unsigned mw = (pos == p.mask_first_pos) ? mword1 : mword0;  // zero when no filter is set
-            if (b < p.B && nvalid && n >= p.arg_first && n <= p.arg_last && !((mw >> (n & 31)) & 1u)) key = argmax_key(v, n);
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                const unsigned long long ok = __shfl_xor(key, o);
-                key = ok > key ? ok : key;
-            }
-            if (b < p.B && nrow == 0) p.tilemax[(long)b * p.n_tiles + tile] = key;
-            if (b < p.B && nvalid && p.out_f32) p.out_f32[(long)b * p.ldo + n] = v;
-            continue;
-        }
-        if (EPI == DE_RESID) {
-            // residual update + this tile's partial LayerNorm statistics of the updated rows
-            float xn = 0.f;
-            if (b < p.B && nvalid) {
-                xn = xold[r] + v;
-                p.out_f32[(long)b * p.ldo + n] = xn;
-            }
-            float s1 = xn, s2 = xn * xn;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                s1 += __shfl_xor(s1, o);
-                s2 += __shfl_xor(s2, o);
-            }
-            if (p.stats_out && nrow == 0) *(float2 *)(p.stats_out + ((long)tile * 16 + b) * 2) = make_float2(s1, s2);
-            continue;
-        }
-        if (b >= p.B || !nvalid) continue;
-        if (EPI == DE_QKV) {
-            const int d = p.N / 3;
-            if (n < d) {
-                p.out_f32[(long)b * d + n] = v;
+        for (int r = 0; r < 4; ++r) {
+            const int bl = kq * 4 + r;
+            const int b = b0 + bl;
+            const bool bvalid = bl < nb;
+            float v;
+            if (LN) {
+                const float2 ms = *(const float2 *)(st + bl * 2);
+                v = __fmaf_rn(ms.x, acc[r], __fmaf_rn(ms.y, c1v, c2v));  // rstd (acc - mean c1) + c2
             } else {
-                const int hn = (n < 2 * d) ? n - d : n - 2 * d;
-                bf16_t *c = (n < 2 * d) ? p.kcache : p.vcache;
-                c[((long)(b * p.n_head + (hn >> 6)) * p.n_ctx + pos) * 64 + (hn & 63)] = f2bf(v);
+                v = acc[r] + c2v;
             }
-        } else if (EPI == DE_Q) {
-            p.out_f32[(long)b * p.ldo + n] = v;
-        } else if (EPI == DE_GELU) {
-            p.out_bf16[(long)b * p.ldo + n] = f2bf(gelu_erf(v));
+            if (EPI == DE_LOGITS && p.ts.rng) {
+                // timestamp rules: best allowed text token, best allowed timestamp, and the (max, sum exp) partial of the
+                // allowed timestamps of this tile (only tiles that reach into the timestamp range carry the last two)
+                const unsigned mw = (pos == p.mask_first_pos) ? mword1 : mword0;
+                const bool ok = bvalid && nvalid && !((mw >> (n & 31)) & 1u);
+                const bool in_text = ok && n >= trng[r].x && n < trng[r].y;
+                const bool in_ts = ok && n >= trng[r].z && n < trng[r].w;
+                unsigned long long kt = in_text ? argmax_key(v, n) : 0ull, ks = in_ts ? argmax_key(v, n) : 0ull;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    const unsigned long long a = __shfl_xor(kt, o), c = __shfl_xor(ks, o);
+                    kt = a > kt ? a : kt;
+                    ks = c > ks ? c : ks;
+                }
+                if (bvalid && nrow == 0) p.tilemax[(long)b * p.n_tiles + tile] = kt;
+                if (n0 + 16 > p.ts.ts_begin) {  // workgroup-uniform
+                    float mx = in_ts ? v : -1e30f;
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                    float se = in_ts ? __expf(v - mx) : 0.f;
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o);
+                    if (bvalid && nrow == 0) {
+                        p.ts.key_ts[(long)b * p.n_tiles + tile] = ks;
+                        *(float2 *)(p.ts.lse + ((long)b * p.n_tiles + tile) * 2) = make_float2(mx, se);
+                    }
+                }
+                if (bvalid && nvalid && p.out_f32) p.out_f32[(long)b * p.ldo + n] = v;
+                continue;
+            }
+            if (EPI == DE_LOGITS) {
+                // arg-max over [arg_first, arg_last], first maximal index wins (Whisper.swift:38)
+                unsigned long long key = 0ull;
+                const unsigned mw = (pos == p.mask_first_pos) ? mword1 : mword0;  // zero when no filter is set
+                if (bvalid && nvalid && n >= p.arg_first && n <= p.arg_last && !((mw >> (n & 31)) & 1u)) key = argmax_key(v, n);
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    const unsigned long long ok = __shfl_xor(key, o);
+                    key = ok > key ? ok : key;
+                }
+                if (bvalid && nrow == 0) p.tilemax[(long)b * p.n_tiles + tile] = key;
+                if (bvalid && nvalid && p.out_f32) p.out_f32[(long)b * p.ldo + n] = v;
+                continue;
+            }
+            if (EPI == DE_RESID) {
+                // residual update (f32 + the bf16 copy the next GEMV multiplies) + this tile's partial LayerNorm
+                // statistics of the updated rows
+                float xn = 0.f;
+                if (bvalid && nvalid) {
+                    xn = xold[r] + v;
+                    p.out_f32[(long)b * p.ldo + n] = xn;
+                    if (p.out_bf16) p.out_bf16[(long)b * p.ldo + n] = f2bf(xn);
+                }
+                float s1 = xn, s2 = xn * xn;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1 += __shfl_xor(s1, o);
+                    s2 += __shfl_xor(s2, o);
+                }
+                if (p.stats_out && nrow == 0)
+                    *(float2 *)(p.stats_out + (long)(b0 >> 4) * p.stats_stride + ((long)tile * 16 + bl) * 2) = make_float2(s1, s2);
+                continue;
+            }
+            if (!bvalid || !nvalid) continue;
+            if (EPI == DE_QKV) {
+                const int d = p.N / 3;
+                if (n < d) {
+                    p.out_f32[(long)b * d + n] = v;
+                } else {
+                    const int hn = (n < 2 * d) ? n - d : n - 2 * d;
+                    bf16_t *c = (n < 2 * d) ? p.kcache : p.vcache;
+                    c[((long)(b * p.n_head + (hn >> 6)) * p.n_ctx + pos) * 64 + (hn & 63)] = f2bf(v);
+                }
+            } else if (EPI == DE_Q) {
+                p.out_f32[(long)b * p.ldo + n] = v;
+            } else if (EPI == DE_GELU) {
+                p.out_bf16[(long)b * p.ldo + n] = f2bf(gelu_erf(v));
+            }
         }
+    }
+}
+
+// LayerNorm folding (wm_finalize): W'[n][k] = bf16(W[n][k] g[k]) in the same WL_TILED order, c1[n] = sum_k W'[n][k],
+// c2[n] = bias[n] + sum_k beta[k] W[n][k].  One workgroup per weight row; fixed summation order.
+__global__ __launch_bounds__(256) void ln_fold_kernel(const bf16_t *__restrict__ W, const float *__restrict__ g,
+                                                      const float *__restrict__ beta, const float *__restrict__ bias,
+                                                      int N, int K, bf16_t *__restrict__ Wf, float *__restrict__ c1,
+                                                      float *__restrict__ c2) {
+    __shared__ float r1[4], r2[4];
+    const int n = blockIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const size_t o = wm_tiled_offset((size_t)n, (size_t)k, (size_t)K);
+        const float w = bf2f(W[o]);
+        const bf16_t wf = f2bf(w * g[k]);
+        Wf[o] = wf;
+        s1 += bf2f(wf);
+        s2 += beta[k] * w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        r1[threadIdx.x >> 6] = s1;
+        r2[threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c1[n] = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+        c2[n] = (n < N && bias ? bias[n] : 0.f) + ((r2[0] + r2[1]) + (r2[2] + r2[3]));
     }
 }
 
@@ -424,7 +372,8 @@ __global__ __launch_bounds__(NW * 64) void dec_gemv_kernel(DecGemvDev p) {
 __global__ __launch_bounds__(256) void dec_embed_kernel(const int *__restrict__ seq, const int *__restrict__ pos_ptr,
                                                         int B, const bf16_t *__restrict__ emb,
                                                         const float *__restrict__ pemb, int d,
-                                                        float *__restrict__ x, float *__restrict__ stats_out) {
+                                                        float *__restrict__ x, bf16_t *__restrict__ xb,
+                                                        float *__restrict__ stats_out) {
     __shared__ float r1[4], r2[4];
     const int b = blockIdx.x;
     const int pos = *pos_ptr;
@@ -433,6 +382,7 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int *__restrict__ 
     for (int j = threadIdx.x; j < d; j += 256) {
         const float v = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)pos * d + j];
         x[(long)b * d + j] = v;
+        xb[(long)b * d + j] = f2bf(v);
         s1 += v;
         s2 += v * v;
     }
@@ -447,9 +397,13 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int *__restrict__ 
     }
     __syncthreads();
     // LayerNorm partial statistics of this row: a single part (index 0)
-    if (threadIdx.x == 0 && stats_out)
-        *(float2 *)(stats_out + (long)(b >> 4) * (2 * d) + (b & 15) * 2) =  // block of 16 rows: [parts][16][2]
-            make_float2((r1[0] + r1[1]) + (r1[2] + r1[3]), (r2[0] + r2[1]) + (r2[2] + r2[3]));
+    // the whole row is ONE part (index 0); the consumers always sum d/16 parts, so the others are zeroed
+    if (stats_out) {
+        float *blk = stats_out + (long)(b >> 4) * (2 * d) + (b & 15) * 2;  // block of 16 rows: [d/16 parts][16][2]
+        for (int pt = 1 + threadIdx.x; pt < d / 16; pt += 256) *(float2 *)(blk + pt * 32) = make_float2(0.f, 0.f);
+        if (threadIdx.x == 0)
+            *(float2 *)blk = make_float2((r1[0] + r1[1]) + (r1[2] + r1[3]), (r2[0] + r2[1]) + (r2[2] + r2[3]));
+    }
 }
 
 // ------------------------------------------------------------------ single-query attention
@@ -751,8 +705,8 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
                                                              int *__restrict__ result, int arg_first,
                                                              const bf16_t *__restrict__ emb,
                                                              const float *__restrict__ pemb, int d, int n_ctx,
-                                                             float *__restrict__ x, float *__restrict__ stats_out,
-                                                             WmTsDev ts) {
+                                                             float *__restrict__ x, bf16_t *__restrict__ xb,
+                                                             float *__restrict__ stats_out, WmTsDev ts) {
     __shared__ int tok_s[WM_DEC_MAXB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pos = pos_ptr ? *pos_ptr : 0;
@@ -844,6 +798,7 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
             for (int j = lane; j < d; j += 64) {
                 const float v = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)(pos + 1) * d + j];
                 x[(long)b * d + j] = v;
+                xb[(long)b * d + j] = f2bf(v);
                 s1 += v;
                 s2 += v * v;
             }
@@ -852,8 +807,11 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
                 s1 += __shfl_xor(s1, o);
                 s2 += __shfl_xor(s2, o);
             }
-            if (lane == 0 && stats_out)
-                *(float2 *)(stats_out + (long)(b >> 4) * (2 * d) + (b & 15) * 2) = make_float2(s1, s2);
+            if (stats_out) {  // one part (index 0) carries the row; the other d/16 - 1 parts the consumers sum are zero
+                float *blk = stats_out + (long)(b >> 4) * (2 * d) + (b & 15) * 2;
+                for (int pt = 1 + lane; pt < d / 16; pt += 64) *(float2 *)(blk + pt * 32) = make_float2(0.f, 0.f);
+                if (lane == 0) *(float2 *)blk = make_float2(s1, s2);
+            }
         }
     }
     if (threadIdx.x == 0 && pos_ptr) *pos_ptr = pos + 1;
@@ -900,23 +858,20 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(void *dst, int is_bf16,
     }
 }
 
-template <int AMODE, int EPI>
-int launch_gemv_b(wm_ctx *ctx, const DecGemvDev &p, int nw, int gx) {
+template <int EPI, bool LN>
+int launch_gemv(wm_ctx *ctx, const DecGemvDev &p, int spw, int nw, int grid) {
     hipStream_t s = ctx->stream;
-    const int bb = p.B < 16 ? p.B : 16;  // rows per batch block (LDS is sized for one block)
-    size_t lds = (size_t)nw * 1024 + 2 * nw * 16 * 4;
-    if (AMODE == DA_LN) lds += (size_t)nw * bb * (p.KC + 8) * 2;
-    lds = (lds + 15) & ~(size_t)15;
-    const int grid = gx;
-    switch (nw) {
-        case 1: dec_gemv_kernel<AMODE, EPI, 1><<<grid, 64, lds, s>>>(p); break;
-        case 2: dec_gemv_kernel<AMODE, EPI, 2><<<grid, 128, lds, s>>>(p); break;
-        case 4: dec_gemv_kernel<AMODE, EPI, 4><<<grid, 256, lds, s>>>(p); break;
-        case 8:
-            if (AMODE == DA_BF16) { dec_gemv_kernel<DA_BF16, EPI, 8><<<grid, 512, lds, s>>>(p); break; }
-        case 16:
-            if (AMODE == DA_BF16) { dec_gemv_kernel<DA_BF16, EPI, 16><<<grid, 1024, lds, s>>>(p); break; }
-        default: wm_set_error("dec_gemv: unsupported wave count %d for this mode", nw); return WM_ERR_INVALID;
+    const size_t lds = (size_t)2 * nw * 1024 + 16 * 2 * 4;
+    const int th = nw * 64;
+    switch (spw) {
+        case 2: dec_gemv_kernel<2, EPI, LN><<<grid, th, lds, s>>>(p); break;
+        case 4: dec_gemv_kernel<4, EPI, LN><<<grid, th, lds, s>>>(p); break;
+        case 5: dec_gemv_kernel<5, EPI, LN><<<grid, th, lds, s>>>(p); break;
+        case 6: dec_gemv_kernel<6, EPI, LN><<<grid, th, lds, s>>>(p); break;
+        case 8: dec_gemv_kernel<8, EPI, LN><<<grid, th, lds, s>>>(p); break;
+        case 10: dec_gemv_kernel<10, EPI, LN><<<grid, th, lds, s>>>(p); break;
+        case 12: dec_gemv_kernel<12, EPI, LN><<<grid, th, lds, s>>>(p); break;
+        default: wm_set_error("dec_gemv: unsupported k-steps per wave %d", spw); return WM_ERR_INVALID;
     }
     WM_HIP(hipGetLastError());
     return WM_OK;
@@ -924,89 +879,105 @@ int launch_gemv_b(wm_ctx *ctx, const DecGemvDev &p, int nw, int gx) {
 
 }  // namespace
 
-// Waves per workgroup (= K splits inside the workgroup).  Target 256..384 k per wave (8..12
-// MFMA k-steps, all issued up front); the LayerNorm prologue needs KC <= 512 and NW <= 4.
-static int g_nw_override = 0;
-void wm_dec_gemv_set_waves_override(int nw) { g_nw_override = nw; }
-static int pick_waves(int K, bool ln, int B) {
-    if (g_nw_override > 0 && K % (32 * g_nw_override) == 0 && (!ln || (g_nw_override <= 4 && K / g_nw_override <= 512)))
-        return g_nw_override;
-    const int maxw = ln ? 4 : 16;
-    int best = 1;
-    for (int nw = 1; nw <= maxw; nw <<= 1)
-        if (K % (32 * nw) == 0 && K / nw >= 256) best = nw;
-    // 16-wave workgroups are one per CU: with more than one batch block the grid (tiles x blocks) no longer fits in a
-    // single round, 8 waves (two workgroups per CU) do (fc2 at B = 16 / 32 / 64: 11.8 / 11.6 / 20.7 -> 11.0 / 10.7 / 17.0 us)
-    if (best == 16 && B > 8) best = 8;
-    return best;
+// Split of K over the waves of a workgroup: a function of K ONLY (never of the batch), so that the order in which a
+// row's sum is formed -- and therefore every logit bit -- does not depend on the decode group the row is in.
+// Returns the wave count; *spw = k-steps (of 32) per wave, one of {2, 4, 5, 6, 8, 10, 12}.
+int wm_dec_gemv_split(int K, int *spw) {
+    const int steps = K / 32;
+    for (int nw = steps >= 96 ? 16 : 8; nw >= 1; --nw) {
+        if (steps % nw) continue;
+        const int s = steps / nw;
+        if (s == 2 || s == 4 || s == 5 || s == 6 || s == 8 || s == 10 || s == 12) {
+            if (spw) *spw = s;
+            return nw;
+        }
+    }
+    return 0;
+}
+
+// Workgroups per weight tile at batch B (a scheduling choice: every row's arithmetic is the same for any value).
+static int pick_bgroups(int B) {
+    static const int env = getenv("WM_GEMV_BG") ? atoi(getenv("WM_GEMV_BG")) : 0;
+    const int nblk = (B + 15) / 16;
+    const int want = env > 0 ? env : 4;
+    return nblk < want ? nblk : want;
 }
 
 int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     WM_REQUIRE(a.B >= 1 && a.B <= WM_DEC_MAXB, WM_ERR_INVALID, "dec_gemv: B=%d out of range", a.B);
     WM_REQUIRE(a.K % 32 == 0, WM_ERR_INVALID, "dec_gemv: K=%d must be a multiple of 32", a.K);
-    const int nw = pick_waves(a.K, a.a_mode == DA_LN, a.B);
-    WM_REQUIRE(a.K % (32 * nw) == 0 && (a.a_mode != DA_LN || a.K / nw <= 512), WM_ERR_INVALID,
-               "dec_gemv: K=%d cannot be split over %d waves", a.K, nw);
-    WM_REQUIRE(a.a_mode != DA_LN || (a.stats_in && a.stats_parts >= 1 && a.stats_parts <= 80), WM_ERR_INVALID,
-               "dec_gemv: LayerNorm mode needs the producer's partial statistics (1..80 parts)");
+    int spw = 0;
+    const int nw = wm_dec_gemv_split(a.K, &spw);
+    WM_REQUIRE(nw >= 1, WM_ERR_INVALID, "dec_gemv: K=%d cannot be split over the waves of a workgroup", a.K);
+    const bool ln = a.c1 != nullptr;
+    WM_REQUIRE(!ln || (a.stats_in && a.K % 64 == 0 && a.K / 16 <= 80), WM_ERR_INVALID,
+               "dec_gemv: LayerNorm mode needs the producer's K/16 partial statistics (K a multiple of 64, <= 1280)");
+    WM_REQUIRE(a.a != nullptr && a.W != nullptr, WM_ERR_INVALID, "dec_gemv: null operand");
     DecGemvDev p;
-    p.B = a.B; p.N = a.N; p.K = a.K; p.KC = a.K / nw;
-    p.W = a.W; p.bias = a.bias; p.x = a.x; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.a_bf16 = a.a_bf16;
-    p.stats_in = a.stats_in; p.stats_parts = a.stats_parts; p.stats_out = a.stats_out;
+    memset(&p, 0, sizeof(p));
+    p.B = a.B; p.N = a.N; p.K = a.K;
+    p.W = a.W; p.c1 = a.c1; p.c2 = a.c2; p.a = a.a;
+    p.stats_in = a.stats_in; p.stats_parts = a.K / 16; p.stats_out = a.stats_out;
     p.stats_stride = 2L * (a.epi == DE_RESID ? a.N : a.K);  // [parts <= d/16][16][2] floats per block of 16 rows
     p.out_f32 = a.out_f32; p.out_bf16 = a.out_bf16;
     p.kcache = a.kcache; p.vcache = a.vcache; p.pos_ptr = a.pos_ptr; p.n_ctx = a.n_ctx; p.n_head = a.n_head;
     p.ldo = a.ldo; p.tilemax = a.argmax; p.arg_first = a.arg_first; p.arg_last = a.arg_last;
     p.mask = a.mask; p.mask_words = a.mask_words; p.mask_first_pos = a.mask_first_pos;
     p.ts = a.ts;
-    const int nblk = (a.B + 15) / 16;
+    p.bgroups = pick_bgroups(a.B);
     p.n_tiles = (a.N + 15) / 16;
-    p.n_tiles_pad = nblk > 1 ? (p.n_tiles + 7) / 8 * 8 : p.n_tiles;  // (tile, block) decode in the kernel needs rows of 8
-    int grid = p.n_tiles_pad * nblk;
+    p.n_tiles_pad = p.bgroups > 1 ? (p.n_tiles + 7) / 8 * 8 : p.n_tiles;  // (tile, group) decode in the kernel needs rows of 8
+    int grid = p.n_tiles_pad * p.bgroups;
     static const bool no_pf = getenv("WM_NO_PREFETCH") != nullptr;
-    p.pf_ptr = nullptr; p.pf_tile_bytes = 0; p.pf_tiles = 0;
     if (!no_pf && a.pf_ptr && a.pf_rows >= 16 && p.n_tiles % 8 == 0) {
         p.pf_ptr = (const char *)a.pf_ptr;
         p.pf_tile_bytes = 16L * a.pf_k * 2;
         p.pf_tiles = a.pf_rows / 16;
         grid += p.pf_tiles;
     }
-    const int key = a.a_mode * 8 + a.epi;
-    switch (key) {
-        case DA_LN * 8 + DE_QKV: {
+    switch (a.epi * 2 + (ln ? 1 : 0)) {
+        case DE_QKV * 2 + 1: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_qkv", ctx->stream);
-            return launch_gemv_b<DA_LN, DE_QKV>(ctx, p, nw, grid);
+            return launch_gemv<DE_QKV, true>(ctx, p, spw, nw, grid);
         }
-        case DA_LN * 8 + DE_Q: {
+        case DE_Q * 2 + 1: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_q", ctx->stream);
-            return launch_gemv_b<DA_LN, DE_Q>(ctx, p, nw, grid);
+            return launch_gemv<DE_Q, true>(ctx, p, spw, nw, grid);
         }
-        case DA_LN * 8 + DE_GELU: {
+        case DE_GELU * 2 + 1: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_fc1", ctx->stream);
-            return launch_gemv_b<DA_LN, DE_GELU>(ctx, p, nw, grid);
+            return launch_gemv<DE_GELU, true>(ctx, p, spw, nw, grid);
         }
-        case DA_LN * 8 + DE_LOGITS: {
+        case DE_LOGITS * 2 + 1: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_logits", ctx->stream);
-            return launch_gemv_b<DA_LN, DE_LOGITS>(ctx, p, nw, grid);
+            return launch_gemv<DE_LOGITS, true>(ctx, p, spw, nw, grid);
         }
-        case DA_BF16 * 8 + DE_RESID: {
+        case DE_RESID * 2: {
             WmProfScope ps(&ctx->prof, a.K > a.N ? "dec_gemv_fc2" : "dec_gemv_attn_out", ctx->stream);
-            return launch_gemv_b<DA_BF16, DE_RESID>(ctx, p, nw, grid);
+            return launch_gemv<DE_RESID, false>(ctx, p, spw, nw, grid);
         }
-        case DA_BF16 * 8 + DE_Q: {
+        case DE_Q * 2: {
             WmProfScope ps(&ctx->prof, "dec_gemv_plain", ctx->stream);
-            return launch_gemv_b<DA_BF16, DE_Q>(ctx, p, nw, grid);
+            return launch_gemv<DE_Q, false>(ctx, p, spw, nw, grid);
         }
         default:
-            wm_set_error("dec_gemv: unsupported mode pair (%d, %d)", a.a_mode, a.epi);
+            wm_set_error("dec_gemv: unsupported (epilogue %d, LayerNorm %d) pair", a.epi, (int)ln);
             return WM_ERR_INVALID;
     }
 }
 
+int wm_ln_fold(wm_ctx *ctx, const bf16_t *W, const float *g, const float *beta, const float *bias, int N, int K,
+               bf16_t *Wf, float *c1, float *c2) {
+    const int npad = (N + 15) / 16 * 16;
+    ln_fold_kernel<<<npad, 256, 0, ctx->stream>>>(W, g, beta, bias, N, K, Wf, c1, c2);
+    WM_HIP(hipGetLastError());
+    return WM_OK;
+}
+
 int wm_dec_embed(wm_ctx *ctx, const int *seq, const int *pos_ptr, int B, const bf16_t *emb, const float *pemb,
-                 int d, float *x, float *stats_out) {
+                 int d, float *x, bf16_t *xb, float *stats_out) {
     WmProfScope ps(&ctx->prof, "dec_embed", ctx->stream);
-    dec_embed_kernel<<<B, 256, 0, ctx->stream>>>(seq, pos_ptr, B, emb, pemb, d, x, stats_out);
+    dec_embed_kernel<<<B, 256, 0, ctx->stream>>>(seq, pos_ptr, B, emb, pemb, d, x, xb, stats_out);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }
@@ -1106,13 +1077,13 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
 
 int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
                     int n_prompt, int *result, int arg_first, const bf16_t *emb, const float *pemb, int d, int n_ctx,
-                    float *x, float *stats_out, const WmTsDev *ts) {
+                    float *x, bf16_t *xb, float *stats_out, const WmTsDev *ts) {
     WmProfScope ps(&ctx->prof, "argmax_embed", ctx->stream);
     WmTsDev t;
     memset(&t, 0, sizeof(t));
     if (ts) t = *ts;
     argmax_embed_kernel<<<1, 1024, 0, ctx->stream>>>(tilemax, n_tiles, B, seq, pos_ptr, n_prompt, result, arg_first,
-                                                     emb, pemb, d, n_ctx, x, stats_out, t);
+                                                     emb, pemb, d, n_ctx, x, xb, stats_out, t);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

@@ -565,7 +565,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
 }  // namespace
 
 static int g_gemm_tile_override = 0;
-extern "C" int wmdbg_set_gemm_tile(int tile) {
+// A/B and parity probes force one of the two tile shapes (the wmdbg_set_gemm_tile hook lives in debug_hooks.cpp)
+int wm_gemm_set_tile_override(int tile) {
     if (tile != 0 && tile != 128 && tile != 256) return WM_ERR_INVALID;
     g_gemm_tile_override = tile;
     return WM_OK;

@@ -46,6 +46,7 @@ static int alloc_decode_buffers(WmModel *m, hipStream_t s) {
     const int d = D.n_text_state;
     // decode-step buffers (batch <= WM_DEC_MAXB)
     WM_TRY(dalloc_t(m, &m->dx, (size_t)WM_DEC_MAXB * d, s));
+    WM_TRY(dalloc_t(m, &m->dxb, (size_t)WM_DEC_MAXB * d, s));
     WM_TRY(dalloc_t(m, &m->dq, (size_t)WM_DEC_MAXB * d, s));
     WM_TRY(dalloc_t(m, &m->dpart, (size_t)WM_DEC_MAXB * D.n_text_head * WM_MAXSPLIT * 66, s));
     WM_TRY(dalloc_t(m, &m->datt, (size_t)WM_DEC_MAXB * d, s));
@@ -129,6 +130,8 @@ int wm_model_create(wm_ctx *ctx, const wm_dims *dims) {
                WM_ERR_INVALID, "head_dim must be 64 (Whisper uses 64 at every size)");
     WM_REQUIRE(D.n_text_ctx >= 8 && D.n_text_ctx <= 448 && D.n_vocab >= 16, WM_ERR_INVALID, "bad text dims");
     WM_REQUIRE(D.n_audio_layer >= 1 && D.n_text_layer >= 1, WM_ERR_INVALID, "bad layer counts");
+    WM_REQUIRE(wm_dec_gemv_split(D.n_text_state, nullptr) > 0 && wm_dec_gemv_split(4 * D.n_text_state, nullptr) > 0,
+               WM_ERR_INVALID, "model width %d: the decode GEMV cannot split K = d / 4d over its waves", D.n_text_state);
     WmModel *m = new WmModel();
     ctx->model = m;
     m->dims = D;
@@ -208,6 +211,12 @@ int wm_model_create(wm_ctx *ctx, const wm_dims *dims) {
         WM_TRY(dalloc_t(m, &L.ln2_g, d, s)); WM_TRY(dalloc_t(m, &L.ln2_b, d, s));
         WM_TRY(dalloc_t(m, &L.w1, (size_t)4 * d * d, s)); WM_TRY(dalloc_t(m, &L.b1, 4 * d, s));
         WM_TRY(dalloc_t(m, &L.w2, (size_t)4 * d * d, s)); WM_TRY(dalloc_t(m, &L.b2, d, s));
+        // LayerNorm-folded decode operands (filled by wm_finalize)
+        WM_TRY(dalloc_t(m, &L.wqkv_f, (size_t)3 * d * d, s)); WM_TRY(dalloc_t(m, &L.wxq_f, (size_t)d * d, s));
+        WM_TRY(dalloc_t(m, &L.w1_f, (size_t)4 * d * d, s));
+        WM_TRY(dalloc_t(m, &L.qkv_c1, 3 * d, s)); WM_TRY(dalloc_t(m, &L.qkv_c2, 3 * d, s));
+        WM_TRY(dalloc_t(m, &L.xq_c1, d, s)); WM_TRY(dalloc_t(m, &L.xq_c2, d, s));
+        WM_TRY(dalloc_t(m, &L.fc1_c1, 4 * d, s)); WM_TRY(dalloc_t(m, &L.fc1_c2, 4 * d, s));
         const std::string p = "decoder.blocks." + std::to_string(i);
         attn_regs(p, L.wqkv, L.bqkv, L.wqkv + (size_t)d * d, L.wqkv + (size_t)2 * d * d, L.bqkv + 2 * d, L.wo,
                   L.bo, L.ln1_g, L.ln1_b, "attn", WL_TILED, WL_TILED, WL_TILED);
@@ -219,6 +228,8 @@ int wm_model_create(wm_ctx *ctx, const wm_dims *dims) {
     WM_TRY(dalloc_t(m, &m->ln_g, d, s)); WM_TRY(dalloc_t(m, &m->ln_b, d, s));
     reg(m, "decoder.ln.weight", m->ln_g, false, d, 2);
     reg(m, "decoder.ln.bias", m->ln_b, false, d, 3);
+    WM_TRY(dalloc_t(m, &m->emb_f, (size_t)m->vpad * d, s));
+    WM_TRY(dalloc_t(m, &m->logit_c1, m->vpad, s)); WM_TRY(dalloc_t(m, &m->logit_c2, m->vpad, s));
 
     WM_TRY(alloc_decode_buffers(m, s));
     WM_HIP(hipStreamSynchronize(s));
@@ -237,6 +248,7 @@ int wm_model_clone(wm_ctx *child, const wm_ctx *parent) {
     m->conv1_w = pm->conv1_w; m->conv2_w = pm->conv2_w; m->conv1_b = pm->conv1_b; m->conv2_b = pm->conv2_b;
     m->enc_pos = pm->enc_pos; m->enc = pm->enc; m->ln_post_g = pm->ln_post_g; m->ln_post_b = pm->ln_post_b;
     m->tok_emb = pm->tok_emb; m->dec_pos = pm->dec_pos; m->dec = pm->dec; m->ln_g = pm->ln_g; m->ln_b = pm->ln_b;
+    m->emb_f = pm->emb_f; m->logit_c1 = pm->logit_c1; m->logit_c2 = pm->logit_c2;
     m->tensors = pm->tensors; m->index = pm->index;   // registry for wm_get_tensor (pointers alias the parent)
     m->shares_weights = true;
     WM_TRY(alloc_decode_buffers(m, child->stream));
@@ -363,8 +375,16 @@ int wm_model_finalize(wm_ctx *ctx) {
     WM_REQUIRE(m, WM_ERR_STATE, "context has no model");
     for (const WmTensor &t : m->tensors)
         WM_REQUIRE(t.set, WM_ERR_STATE, "tensor '%s' was never set", t.name.c_str());
-    // QKV fusion and conv-tap permutation happen at set time (tensors are written straight
-    // into their fused / permuted HBM locations); nothing left to do but mark ready.
+    // QKV fusion and conv-tap permutation happen at set time (tensors are written straight into their fused / permuted
+    // HBM locations).  What is left: the LayerNorm-folded copies the decode GEMVs multiply (model.h, DecLayerW).
+    const int d = m->dims.n_text_state;
+    for (DecLayerW &L : m->dec) {
+        WM_TRY(wm_ln_fold(ctx, L.wqkv, L.ln1_g, L.ln1_b, L.bqkv, 3 * d, d, L.wqkv_f, L.qkv_c1, L.qkv_c2));
+        WM_TRY(wm_ln_fold(ctx, L.wxq, L.lnx_g, L.lnx_b, L.bxq, d, d, L.wxq_f, L.xq_c1, L.xq_c2));
+        WM_TRY(wm_ln_fold(ctx, L.w1, L.ln2_g, L.ln2_b, L.b1, 4 * d, d, L.w1_f, L.fc1_c1, L.fc1_c2));
+    }
+    WM_TRY(wm_ln_fold(ctx, m->tok_emb, m->ln_g, m->ln_b, nullptr, m->dims.n_vocab, d, m->emb_f, m->logit_c1, m->logit_c2));
+    WM_HIP(hipStreamSynchronize(ctx->stream));
     m->finalized = true;
     return WM_OK;
 }
@@ -509,7 +529,6 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
     const int ns = wm_dec_attn_splits(B, H);
     static const int env_xns = getenv("WM_XATTN_SPLITS") ? atoi(getenv("WM_XATTN_SPLITS")) : 0;  // A/B probe
     const int xns = env_xns > 0 ? env_xns : ns;
-    int parts = 1;  // who wrote the residual stream last: embedding (1 part) or a DE_RESID GEMV (d/16 parts)
     for (int l = 0; l < D.n_text_layer; ++l) {
         const DecLayerW &L = m->dec[l];
         bf16_t *kc = m->skv + (size_t)(l * 2 + 0) * B * H * T * 64;
@@ -517,55 +536,54 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         const bf16_t *xk = m->xkv + (size_t)(l * 2 + 0) * B * H * S * 64;
         const bf16_t *xv = m->xkv + (size_t)(l * 2 + 1) * B * H * S * 64;
         DecGemvArgs a;
-        // 1. attn_ln + fused q|k|v projection; k, v appended to the self-attention cache
+        // 1. attn_ln (folded) + fused q|k|v projection; k, v appended to the self-attention cache
         memset(&a, 0, sizeof(a));
-        a.a_mode = DA_LN; a.epi = DE_QKV; a.B = B; a.N = 3 * d; a.K = d; a.W = L.wqkv; a.bias = L.bqkv;
-        a.x = m->dx; a.ln_g = L.ln1_g; a.ln_b = L.ln1_b; a.out_f32 = m->dq; a.kcache = kc; a.vcache = vc;
-        a.stats_in = m->dstats; a.stats_parts = parts;
+        a.epi = DE_QKV; a.B = B; a.N = 3 * d; a.K = d; a.W = L.wqkv_f; a.c1 = L.qkv_c1; a.c2 = L.qkv_c2;
+        a.a = m->dxb; a.out_f32 = m->dq; a.kcache = kc; a.vcache = vc;
+        a.stats_in = m->dstats;
         a.pos_ptr = m->dpos; a.n_ctx = T; a.n_head = H;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 2. causal self-attention over positions 0..pos
         WM_TRY(wm_dec_self_attention(ctx, m->dq, kc, vc, B, H, T, 0, m->dpos, m->datt, L.wo, d, d));
-        // 3. out-projection + residual
+        // 3. out-projection + residual (f32 stream, its bf16 copy, partial statistics)
         memset(&a, 0, sizeof(a));
-        a.a_mode = DA_BF16; a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wo; a.bias = L.bo;
-        a.a_bf16 = m->datt; a.out_f32 = m->dx; a.ldo = d; a.stats_out = m->dstats;
-        a.pf_ptr = L.wxq; a.pf_rows = d; a.pf_k = d;
+        a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wo; a.c2 = L.bo;
+        a.a = m->datt; a.out_f32 = m->dx; a.out_bf16 = m->dxb; a.ldo = d; a.stats_out = m->dstats;
+        a.pf_ptr = L.wxq_f; a.pf_rows = d; a.pf_k = d;
         WM_TRY(wm_dec_gemv(ctx, a));
-        parts = d / 16;
-        // 4. cross_attn_ln + query projection
+        // 4. cross_attn_ln (folded) + query projection
         memset(&a, 0, sizeof(a));
-        a.a_mode = DA_LN; a.epi = DE_Q; a.B = B; a.N = d; a.K = d; a.W = L.wxq; a.bias = L.bxq;
-        a.x = m->dx; a.ln_g = L.lnx_g; a.ln_b = L.lnx_b; a.out_f32 = m->dq; a.ldo = d;
-        a.stats_in = m->dstats; a.stats_parts = parts;
+        a.epi = DE_Q; a.B = B; a.N = d; a.K = d; a.W = L.wxq_f; a.c1 = L.xq_c1; a.c2 = L.xq_c2;
+        a.a = m->dxb; a.out_f32 = m->dq; a.ldo = d;
+        a.stats_in = m->dstats;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 5. cross-attention over the 1500 cached encoder frames
         WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, xns, m->dpart, m->datt, true, L.wxo, d, d));
         // 6. out-projection + residual
         memset(&a, 0, sizeof(a));
-        a.a_mode = DA_BF16; a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wxo; a.bias = L.bxo;
-        a.a_bf16 = m->datt; a.out_f32 = m->dx; a.ldo = d; a.stats_out = m->dstats;
-        a.pf_ptr = L.w1; a.pf_rows = 4 * d; a.pf_k = d;
+        a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wxo; a.c2 = L.bxo;
+        a.a = m->datt; a.out_f32 = m->dx; a.out_bf16 = m->dxb; a.ldo = d; a.stats_out = m->dstats;
+        a.pf_ptr = L.w1_f; a.pf_rows = 4 * d; a.pf_k = d;
         WM_TRY(wm_dec_gemv(ctx, a));
-        // 7. mlp_ln + fc1 + GELU
+        // 7. mlp_ln (folded) + fc1 + GELU
         memset(&a, 0, sizeof(a));
-        a.a_mode = DA_LN; a.epi = DE_GELU; a.B = B; a.N = 4 * d; a.K = d; a.W = L.w1; a.bias = L.b1;
-        a.x = m->dx; a.ln_g = L.ln2_g; a.ln_b = L.ln2_b; a.out_bf16 = m->dhid; a.ldo = 4 * d;
-        a.stats_in = m->dstats; a.stats_parts = parts;
+        a.epi = DE_GELU; a.B = B; a.N = 4 * d; a.K = d; a.W = L.w1_f; a.c1 = L.fc1_c1; a.c2 = L.fc1_c2;
+        a.a = m->dxb; a.out_bf16 = m->dhid; a.ldo = 4 * d;
+        a.stats_in = m->dstats;
         a.pf_ptr = L.w2; a.pf_rows = d; a.pf_k = 4 * d;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 8. fc2 + residual
         memset(&a, 0, sizeof(a));
-        a.a_mode = DA_BF16; a.epi = DE_RESID; a.B = B; a.N = d; a.K = 4 * d; a.W = L.w2; a.bias = L.b2;
-        a.a_bf16 = m->dhid; a.out_f32 = m->dx; a.ldo = d; a.stats_out = m->dstats;
-        if (l + 1 < D.n_text_layer) { a.pf_ptr = m->dec[l + 1].wqkv; a.pf_rows = 3 * d; a.pf_k = d; }
+        a.epi = DE_RESID; a.B = B; a.N = d; a.K = 4 * d; a.W = L.w2; a.c2 = L.b2;
+        a.a = m->dhid; a.out_f32 = m->dx; a.out_bf16 = m->dxb; a.ldo = d; a.stats_out = m->dstats;
+        if (l + 1 < D.n_text_layer) { a.pf_ptr = m->dec[l + 1].wqkv_f; a.pf_rows = 3 * d; a.pf_k = d; }
         WM_TRY(wm_dec_gemv(ctx, a));
     }
-    {   // final LayerNorm + tied-embedding logits + fused per-tile arg-max
+    {   // final LayerNorm (folded) + tied-embedding logits + fused per-tile arg-max
         DecGemvArgs a;
         memset(&a, 0, sizeof(a));
-        a.a_mode = DA_LN; a.epi = DE_LOGITS; a.B = B; a.N = D.n_vocab; a.K = d; a.W = m->tok_emb;
-        a.x = m->dx; a.ln_g = m->ln_g; a.ln_b = m->ln_b; a.stats_in = m->dstats; a.stats_parts = parts;
+        a.epi = DE_LOGITS; a.B = B; a.N = D.n_vocab; a.K = d; a.W = m->emb_f; a.c1 = m->logit_c1; a.c2 = m->logit_c2;
+        a.a = m->dxb; a.stats_in = m->dstats;
         a.out_f32 = want_logits ? m->dlogits : nullptr; a.ldo = m->vpad;
         a.argmax = m->dargmax; a.arg_first = arg_first; a.arg_last = arg_last;
         if (mask_first_pos >= 0) {
@@ -579,13 +597,13 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
 
 int wm_model_embed_first(wm_ctx *ctx, int B) {
     WmModel *m = ctx->model;
-    return wm_dec_embed(ctx, m->dseq, m->dpos, B, m->tok_emb, m->dec_pos, m->dims.n_text_state, m->dx, m->dstats);
+    return wm_dec_embed(ctx, m->dseq, m->dpos, B, m->tok_emb, m->dec_pos, m->dims.n_text_state, m->dx, m->dxb, m->dstats);
 }
 
 int wm_model_close_step(wm_ctx *ctx, int B, int n_prompt, bool write_seq, int *result, int arg_first, bool use_ts) {
     WmModel *m = ctx->model;
     const WmTsDev t = wm_model_ts_dev(m);
     return wm_argmax_embed(ctx, m->dargmax, m->vpad / 16, B, write_seq ? m->dseq : nullptr, m->dpos, n_prompt, result,
-                           arg_first, m->tok_emb, m->dec_pos, m->dims.n_text_state, m->dims.n_text_ctx, m->dx,
+                           arg_first, m->tok_emb, m->dec_pos, m->dims.n_text_state, m->dims.n_text_ctx, m->dx, m->dxb,
                            m->dstats, use_ts ? &t : nullptr);
 }

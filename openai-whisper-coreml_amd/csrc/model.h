@@ -38,6 +38,10 @@ struct DecLayerW {
     float *b1;
     bf16_t *w2;
     float *b2;
+    // LayerNorm-folded copies built by wm_finalize (decode GEMV operands): W' = bf16(W g), c1[n] = sum_k W'[n][k],
+    // c2[n] = bias[n] + sum_k beta[k] W[n][k] -- so that LN(x) W^T + b = rstd (x W'^T - mean c1) + c2
+    bf16_t *wqkv_f, *wxq_f, *w1_f;
+    float *qkv_c1, *qkv_c2, *xq_c1, *xq_c2, *fc1_c1, *fc1_c2;
 };
 
 // One registry entry per openai-whisper state-dict key: where its elements live in HBM.
@@ -89,6 +93,8 @@ struct WmModel {
     float *dec_pos = nullptr;   // [n_text_ctx][d]
     std::vector<DecLayerW> dec;
     float *ln_g = nullptr, *ln_b = nullptr;
+    bf16_t *emb_f = nullptr;    // [vpad][d] token embedding with the final LayerNorm's gamma folded in (logits GEMV)
+    float *logit_c1 = nullptr, *logit_c2 = nullptr;  // [vpad]
     std::vector<void *> allocs;
     std::vector<WmTensor> tensors;
     std::map<std::string, int> index;
@@ -107,7 +113,8 @@ struct WmModel {
     bf16_t *xkv = nullptr;    // [L][2][B][H][1500][64]  cross-attention K/V cache
     bf16_t *skv = nullptr;    // [L][2][B][H][n_text_ctx][64] self-attention K/V cache
     // decode-step buffers
-    float *dx = nullptr;        // [16][d]   decoder residual stream
+    float *dx = nullptr;        // [B][d]    decoder residual stream (f32)
+    bf16_t *dxb = nullptr;      // [B][d]    its bf16 copy: the A operand of the LayerNorm-folded GEMVs
     float *dq = nullptr;        // [16][d]   query (self or cross)
     float *dpart = nullptr;     // [16][H][WM_MAXSPLIT][66] attention partials (m, l, o[64])
     float *dstats = nullptr;    // [B/16][d/16][16][2] LayerNorm partial statistics of the residual stream
@@ -204,23 +211,20 @@ int wm_enc_attention(wm_ctx *ctx, const bf16_t *qk, const bf16_t *vt, bf16_t *at
 // dec_kernels.hip
 constexpr int WM_DEC_MAXB = 128;  // decode group: up to eight batch blocks of 16 rows (the MFMA M dimension)
 constexpr int WM_MAXSPLIT = 8;  // flash-decoding splits of single-query attention (small batches)
-enum DecAMode { DA_LN = 0, DA_BF16 = 1 };
 enum DecEpi { DE_QKV = 0, DE_Q = 1, DE_RESID = 2, DE_GELU = 3, DE_LOGITS = 4 };
 struct DecGemvArgs {
-    int a_mode, epi;
+    int epi;
     int B, N, K;
-    const bf16_t *W;    // [N (padded to 16)][K] in WL_TILED order
-    const float *bias;  // [N] or null
-    // A operand
-    const float *x;        // DA_LN: residual stream [B][K]
-    const float *ln_g, *ln_b;
-    const float *stats_in; // DA_LN: [stats_parts][16][2] partial (sum, sum of squares) per row, from the producer of x
-    int stats_parts;
-    float *stats_out;      // DE_RESID: [N/16][16][2] partials of the updated residual (may be null)
-    const bf16_t *a_bf16;  // DA_BF16: [B][K]
+    const bf16_t *W;    // [N (padded to 16)][K] in WL_TILED order; LayerNorm mode: the gamma-folded copy
+    const float *c1;    // LayerNorm mode (non-null): column sums of the folded weights, see DecLayerW
+    const float *c2;    // [N] bias (LayerNorm mode: + beta fold) or null
+    const bf16_t *a;    // [B][K] bf16 activations
+    const float *stats_in; // LayerNorm mode: [B/16][K/16][16][2] partial (sum, sum of squares) per row of the f32 residual,
+    int stats_parts;       //                 from the producer of the residual (always K/16 parts; unused ones are zero)
+    float *stats_out;      // DE_RESID: [B/16][N/16][16][2] partials of the updated residual (may be null)
     // outputs
-    float *out_f32;        // DE_Q: [B][N]; DE_RESID: residual [B][N] (+=); DE_LOGITS: [B][ldo]
-    bf16_t *out_bf16;      // DE_GELU: [B][N]
+    float *out_f32;        // DE_QKV: q [B][N/3]; DE_Q: [B][ldo]; DE_RESID: residual [B][ldo] (+=); DE_LOGITS: [B][ldo] or null
+    bf16_t *out_bf16;      // DE_GELU: [B][ldo]; DE_RESID: bf16 copy of the updated residual (may be null)
     bf16_t *kcache, *vcache;  // DE_QKV: this layer's [B][H][T][64]
     const int *pos_ptr;       // device-side decode position (DE_QKV appends at *pos_ptr)
     int n_ctx, n_head;
@@ -237,9 +241,14 @@ struct DecGemvArgs {
     int pf_rows, pf_k;
 };
 int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a);
+// waves per workgroup and k-steps per wave the GEMV uses for a given K (a function of K only)
+int wm_dec_gemv_split(int K, int *spw);
+// W' = bf16(W g) (WL_TILED in, WL_TILED out), c1 = row sums of W', c2 = bias + W beta; rows N .. pad16(N) give zeros
+int wm_ln_fold(wm_ctx *ctx, const bf16_t *W, const float *g, const float *beta, const float *bias /*nullable*/, int N,
+               int K, bf16_t *Wf, float *c1, float *c2);
 // x[b] = token_embedding[seq[*pos_ptr][b]] + positional_embedding[*pos_ptr]
 int wm_dec_embed(wm_ctx *ctx, const int *seq, const int *pos_ptr, int B, const bf16_t *emb, const float *pemb,
-                 int d, float *x, float *stats_out);
+                 int d, float *x, bf16_t *xb, float *stats_out);
 // Single-query attention over a K/V cache [B][H][T_stride][64] -> bf16 head outputs att[B][H*64].
 // Keys 0 .. n-1 with n = *pos_ptr + 1 when pos_ptr != null, else n_keys.
 int wm_dec_attn_splits(int B, int H);
@@ -256,7 +265,7 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
 // partial statistics) when x != null; then *pos_ptr += 1.  seq / pos_ptr / result / x may be null.
 int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
                     int n_prompt, int *result, int arg_first, const bf16_t *emb, const float *pemb, int d, int n_ctx,
-                    float *x, float *stats_out, const WmTsDev *ts = nullptr);
+                    float *x, bf16_t *xb, float *stats_out, const WmTsDev *ts = nullptr);
 // initial timestamp-rule state of B sequences (before the first sampled token)
 int wm_ts_init(wm_ctx *ctx, const WmTsDev &ts, int B);
 int wm_range_softmax(wm_ctx *ctx, const float *logits, long ldo, int B, int first, int n, float *probs);

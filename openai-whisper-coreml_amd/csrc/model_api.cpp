@@ -1,7 +1,7 @@
 // model_api.cpp -- boundary #2 of the C ABI (include/whisper_mi355x.h): weight loading, the
 // encoder / decoder entry points that replace the CoreML `encoder` / `decoder` classes
 // (Whisper/Whisper/Whisper.swift:17-40), the KV-cached greedy transcription asked for by
-// BASELINE.json, and the per-kernel test hooks (include/whisper_mi355x_debug.h).
+// BASELINE.json.  (The per-kernel test hooks live in debug_hooks.cpp, which is NOT part of the product library.)
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -10,7 +10,6 @@
 
 #include <vector>
 
-#include "../../include/whisper_mi355x_debug.h"
 #include "model.h"
 
 #define WM_MODEL(ctx)                                                               \
@@ -238,7 +237,7 @@ static int detect_language_impl(wm_ctx *ctx, const float *xa, int B, int32_t sot
     WM_TRY(wm_model_embed_first(ctx, B));
     WM_TRY(wm_model_decode_step(ctx, B, probs != nullptr, lang_first, lang_last));     // :36-37
     WM_TRY(wm_argmax_embed(ctx, m->dargmax, m->vpad / 16, B, nullptr, nullptr, 0, m->dresult, lang_first, nullptr,
-                           nullptr, 0, 0, nullptr, nullptr));               // :38
+                           nullptr, 0, 0, nullptr, nullptr, nullptr));      // :38
     if (probs) {  // openai-whisper detect_language(): softmax over the language-token logits only
         const int n_lang = lang_last - lang_first + 1;
         float *d_probs = probs;
@@ -450,436 +449,5 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
         }
         for (int i = 0; i < 3; ++i) ctx->stage_ms[i] += wave_ms[i];  // lanes overlap: slowest lane per stage
     }
-    return WM_OK;
-}
-
-// ------------------------------------------------------------------ per-kernel test hooks
-static int up(void **d, const void *h, size_t bytes, hipStream_t s) {
-    WM_HIP(hipMalloc(d, bytes + 512));
-    WM_HIP(hipMemsetAsync(*d, 0, bytes + 512, s));
-    if (h) WM_HIP(hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, s));
-    return WM_OK;
-}
-static void to_bf16(const float *in, std::vector<bf16_t> &out, size_t n) {
-    out.resize(n);
-    for (size_t i = 0; i < n; ++i) {
-        uint32_t u;
-        memcpy(&u, &in[i], 4);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        out[i] = (bf16_t)(u >> 16);
-    }
-}
-static void from_bf16(const std::vector<bf16_t> &in, float *out) {
-    for (size_t i = 0; i < in.size(); ++i) {
-        uint32_t u = (uint32_t)in[i] << 16;
-        memcpy(&out[i], &u, 4);
-    }
-}
-
-extern "C" int wmdbg_gemm(wm_ctx *ctx, const float *A, const float *W, const float *bias, float *C, int M, int N,
-                          int K, int epi) {
-    WM_TRY(wm_ctx_make_current(ctx));
-    WM_REQUIRE(epi == EPI_F32 || epi == EPI_BIAS_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_F32, WM_ERR_INVALID,
-               "wmdbg_gemm: epilogue %d not exposed", epi);
-    std::vector<bf16_t> a16, w16;
-    to_bf16(A, a16, (size_t)M * K);
-    to_bf16(W, w16, (size_t)N * K);
-    void *dA, *dW, *dB = nullptr, *dC;
-    hipStream_t s = ctx->stream;
-    WM_TRY(up(&dA, a16.data(), a16.size() * 2, s));
-    WM_TRY(up(&dW, w16.data(), w16.size() * 2, s));
-    if (bias) WM_TRY(up(&dB, bias, (size_t)N * 4, s));
-    const bool f32out = (epi == EPI_F32 || epi == EPI_RESID_F32);
-    WM_TRY(up(&dC, epi == EPI_RESID_F32 ? C : nullptr, (size_t)M * N * (f32out ? 4 : 2), s));
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.A = (const bf16_t *)dA; g.a_rpb = (long)M + 1; g.a_rstride = K;
-    g.W = (const bf16_t *)dW; g.bias = (const float *)dB; g.C = dC;
-    g.c_rpb = (long)M + 1; g.c_rstride = N; g.M = M; g.N = N; g.K = K; g.epi = epi;
-    int rc = wm_gemm(ctx, g);
-    if (rc == WM_OK) {
-        if (f32out) {
-            WM_HIP(hipMemcpyAsync(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost, s));
-            WM_HIP(hipStreamSynchronize(s));
-        } else {
-            std::vector<bf16_t> c16((size_t)M * N);
-            WM_HIP(hipMemcpyAsync(c16.data(), dC, c16.size() * 2, hipMemcpyDeviceToHost, s));
-            WM_HIP(hipStreamSynchronize(s));
-            from_bf16(c16, C);
-        }
-    }
-    (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC);
-    if (dB) (void)hipFree(dB);
-    return rc;
-}
-
-extern "C" int wmdbg_layernorm(wm_ctx *ctx, const float *x, const float *g, const float *b, int rows, int d,
-                               float *out_f32, float *out_bf16_as_f32) {
-    WM_TRY(wm_ctx_make_current(ctx));
-    void *dx, *dg, *db, *of, *ob;
-    hipStream_t s = ctx->stream;
-    WM_TRY(up(&dx, x, (size_t)rows * d * 4, s));
-    WM_TRY(up(&dg, g, (size_t)d * 4, s));
-    WM_TRY(up(&db, b, (size_t)d * 4, s));
-    WM_TRY(up(&of, nullptr, (size_t)rows * d * 4, s));
-    WM_TRY(up(&ob, nullptr, (size_t)rows * d * 2, s));
-    int rc = wm_layernorm(ctx, (const float *)dx, (const float *)dg, (const float *)db, rows, d, (bf16_t *)ob, (float *)of);
-    if (rc == WM_OK) {
-        std::vector<bf16_t> t((size_t)rows * d);
-        WM_HIP(hipMemcpyAsync(out_f32, of, (size_t)rows * d * 4, hipMemcpyDeviceToHost, s));
-        WM_HIP(hipMemcpyAsync(t.data(), ob, t.size() * 2, hipMemcpyDeviceToHost, s));
-        WM_HIP(hipStreamSynchronize(s));
-        from_bf16(t, out_bf16_as_f32);
-    }
-    (void)hipFree(dx); (void)hipFree(dg); (void)hipFree(db); (void)hipFree(of); (void)hipFree(ob);
-    return rc;
-}
-
-// Encoder attention on host q, k, v given as f32 [B][S][H*64] each (rounded to bf16 inside).
-extern "C" int wmdbg_enc_attention(wm_ctx *ctx, const float *q, const float *k, const float *v, int B, int H, int S,
-                                   float *out) {
-    WM_TRY(wm_ctx_make_current(ctx));
-    const int d = H * 64, S_pad = ((S + 63) / 64) * 64;
-    const size_t M = (size_t)B * S;
-    std::vector<bf16_t> qk((M + 64) * 2 * d, 0), vt((size_t)B * H * 64 * S_pad, 0), tmp;
-    auto bf = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); };
-    for (size_t mrow = 0; mrow < M; ++mrow)
-        for (int j = 0; j < d; ++j) {
-            qk[mrow * 2 * d + j] = bf(q[mrow * d + j]);
-            qk[mrow * 2 * d + d + j] = bf(k[mrow * d + j]);
-        }
-    for (int b = 0; b < B; ++b)
-        for (int s = 0; s < S; ++s)
-            for (int j = 0; j < d; ++j)
-                vt[((size_t)(b * H + j / 64) * 64 + j % 64) * S_pad + s] = bf(v[((size_t)b * S + s) * d + j]);
-    void *dqk, *dvt, *datt;
-    hipStream_t st = ctx->stream;
-    WM_TRY(up(&dqk, qk.data(), qk.size() * 2, st));
-    WM_TRY(up(&dvt, vt.data(), vt.size() * 2, st));
-    WM_TRY(up(&datt, nullptr, M * d * 2, st));
-    int rc = wm_enc_attention(ctx, (const bf16_t *)dqk, (const bf16_t *)dvt, (bf16_t *)datt, B, H, S, S_pad, d);
-    if (rc == WM_OK) {
-        tmp.resize(M * d);
-        WM_HIP(hipMemcpyAsync(tmp.data(), datt, tmp.size() * 2, hipMemcpyDeviceToHost, st));
-        WM_HIP(hipStreamSynchronize(st));
-        from_bf16(tmp, out);
-    }
-    (void)hipFree(dqk); (void)hipFree(dvt); (void)hipFree(datt);
-    return rc;
-}
-
-// Skinny decode GEMV: out[B][N] = LN?(x)[B][K] . W[N][K]^T + bias (a_mode DA_LN or DA_BF16, epilogue DE_Q).
-extern "C" int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, const float *ln_b, const float *W,
-                              const float *bias, float *out, int B, int N, int K) {
-    WM_TRY(wm_ctx_make_current(ctx));
-    WM_REQUIRE(B >= 1 && B <= 16, WM_ERR_INVALID, "wmdbg_dec_gemv: one batch block (B <= 16)");
-    const int Npad = ((N + 15) / 16) * 16;
-    std::vector<bf16_t> w16, x16;
-    std::vector<float> wp((size_t)Npad * K, 0.f);   // fragment-tiled order (WL_TILED)
-    for (size_t r = 0; r < (size_t)N; ++r)
-        for (size_t k = 0; k < (size_t)K; ++k) wp[wm_tiled_offset(r, k, (size_t)K)] = W[r * K + k];
-    to_bf16(wp.data(), w16, wp.size());
-    void *dx, *dx16 = nullptr, *dg = nullptr, *db = nullptr, *dW, *dbias = nullptr, *dout;
-    hipStream_t s = ctx->stream;
-    WM_TRY(up(&dx, x, (size_t)B * K * 4, s));
-    WM_TRY(up(&dW, w16.data(), w16.size() * 2, s));
-    WM_TRY(up(&dout, nullptr, (size_t)B * N * 4, s));
-    if (bias) WM_TRY(up(&dbias, bias, (size_t)N * 4, s));
-    DecGemvArgs a;
-    memset(&a, 0, sizeof(a));
-    a.B = B; a.N = N; a.K = K; a.W = (const bf16_t *)dW; a.bias = (const float *)dbias;
-    a.out_f32 = (float *)dout; a.ldo = N; a.epi = DE_Q; a.pos_ptr = nullptr;
-    void *dst = nullptr;
-    if (ln_g) {
-        WM_TRY(up(&dg, ln_g, (size_t)K * 4, s));
-        WM_TRY(up(&db, ln_b, (size_t)K * 4, s));
-        // the producer's partial statistics: here 3 uneven parts computed on the host
-        std::vector<float> st(3 * 16 * 2, 0.f);
-        for (int b = 0; b < B; ++b)
-            for (int k = 0; k < K; ++k) {
-                const int part = k < K / 4 ? 0 : (k < K / 2 ? 1 : 2);
-                const float v = x[(size_t)b * K + k];
-                st[(part * 16 + b) * 2] += v;
-                st[(part * 16 + b) * 2 + 1] += v * v;
-            }
-        WM_TRY(up(&dst, st.data(), st.size() * 4, s));
-        a.stats_in = (const float *)dst; a.stats_parts = 3;
-        a.a_mode = DA_LN; a.x = (const float *)dx; a.ln_g = (const float *)dg; a.ln_b = (const float *)db;
-    } else {
-        to_bf16(x, x16, (size_t)B * K);
-        WM_TRY(up(&dx16, x16.data(), x16.size() * 2, s));
-        a.a_mode = DA_BF16; a.a_bf16 = (const bf16_t *)dx16;
-    }
-    int rc = wm_dec_gemv(ctx, a);
-    if (rc == WM_OK) {
-        WM_HIP(hipMemcpyAsync(out, dout, (size_t)B * N * 4, hipMemcpyDeviceToHost, s));
-        WM_HIP(hipStreamSynchronize(s));
-    }
-    void *fr[] = {dx, dx16, dg, db, dW, dbias, dout, dst};
-    for (void *p : fr)
-        if (p) (void)hipFree(p);
-    return rc;
-}
-
-// Single-query attention: q f32 [B][H*64], k/v f32 [B][H][T][64] (rounded to bf16), first
-// n_keys positions, `nsplit` flash-decoding splits; out f32 [B][H*64] (partials combined on host).
-extern "C" int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, const float *v, int B, int H, int T,
-                                   int n_keys, int nsplit, float *out) {
-    WM_TRY(wm_ctx_make_current(ctx));
-    std::vector<bf16_t> k16, v16;
-    to_bf16(k, k16, (size_t)B * H * T * 64);
-    to_bf16(v, v16, (size_t)B * H * T * 64);
-    void *dq, *dk, *dv, *dp;
-    hipStream_t s = ctx->stream;
-    WM_TRY(up(&dq, q, (size_t)B * H * 64 * 4, s));
-    WM_TRY(up(&dk, k16.data(), k16.size() * 2, s));
-    WM_TRY(up(&dv, v16.data(), v16.size() * 2, s));
-    WM_TRY(up(&dp, nullptr, (size_t)B * H * (nsplit > 0 ? nsplit : 1) * 66 * 4, s));
-    void *datt;
-    WM_TRY(up(&datt, nullptr, (size_t)B * H * 64 * 2, s));
-    // nsplit == 0 selects the decoder's self-attention kernel (one 4-wave workgroup per pair), nsplit == -1 the
-    // cross-attention launch path (8-wave block-streaming kernel, capped grid)
-    int rc = nsplit == 0 ? wm_dec_self_attention(ctx, (const float *)dq, (const bf16_t *)dk, (const bf16_t *)dv, B, H, T,
-                                                 n_keys, nullptr, (bf16_t *)datt)
-                         : wm_dec_attention(ctx, (const float *)dq, (const bf16_t *)dk, (const bf16_t *)dv, B, H, T, n_keys,
-                                            nullptr, nsplit < 0 ? 1 : nsplit, (float *)dp, (bf16_t *)datt, nsplit < 0);
-    if (rc == WM_OK) {
-        std::vector<bf16_t> o16((size_t)B * H * 64);
-        WM_HIP(hipMemcpyAsync(o16.data(), datt, o16.size() * 2, hipMemcpyDeviceToHost, s));
-        WM_HIP(hipStreamSynchronize(s));
-        from_bf16(o16, out);
-    }
-    (void)hipFree(datt);
-    (void)hipFree(dq); (void)hipFree(dk); (void)hipFree(dv); (void)hipFree(dp);
-    return rc;
-}
-
-// ------------------------------------------------------------------ micro-benchmarks ------
-// Time `iters` back-to-back launches of one decode kernel, cycling over `n_mats` distinct weight
-// matrices / cache slices so nothing is served from L2 or MALL.  Returns average microseconds
-// per launch (HIP events on the context's stream).
-void wm_dec_gemv_set_waves_override(int nw);
-
-extern "C" int wmdbg_bench_dec_gemv(wm_ctx *ctx, int B, int N, int K, int ln, int resid, int n_mats, int iters,
-                                    int nw_override, float *avg_us) {
-    WM_TRY(wm_ctx_make_current(ctx));
-    WM_REQUIRE(B >= 1 && B <= WM_DEC_MAXB, WM_ERR_INVALID, "wmdbg_bench_dec_gemv: B out of range");
-    hipStream_t s = ctx->stream;
-    const int Npad = ((N + 15) / 16) * 16;
-    void *dW, *dx, *dx16, *dg, *db, *dout;
-    WM_TRY(up(&dW, nullptr, (size_t)n_mats * Npad * K * 2, s));
-    WM_TRY(up(&dx, nullptr, (size_t)WM_DEC_MAXB * K * 4, s));
-    WM_TRY(up(&dx16, nullptr, (size_t)WM_DEC_MAXB * K * 2, s));
-    WM_TRY(up(&dg, nullptr, (size_t)K * 4, s));
-    WM_TRY(up(&db, nullptr, (size_t)K * 4, s));
-    WM_TRY(up(&dout, nullptr, (size_t)WM_DEC_MAXB * Npad * 4, s));
-    WM_HIP(hipMemsetAsync(dW, 0x3c, (size_t)n_mats * Npad * K * 2, s));
-    DecGemvArgs a;
-    memset(&a, 0, sizeof(a));
-    a.B = B; a.N = N; a.K = K; a.out_f32 = (float *)dout; a.ldo = Npad; a.epi = resid ? DE_RESID : DE_Q;
-    void *dstat;
-    WM_TRY(up(&dstat, nullptr, (size_t)(WM_DEC_MAXB / 16) * 2 * (K > N ? K : N) * 4 + 4096, s));
-    if (resid) a.stats_out = (float *)dstat;
-    if (ln) { a.a_mode = DA_LN; a.x = (const float *)dx; a.ln_g = (const float *)dg; a.ln_b = (const float *)db;
-              a.stats_in = (const float *)dstat; a.stats_parts = K / 16; }
-    else { a.a_mode = DA_BF16; a.a_bf16 = (const bf16_t *)dx16; }
-    wm_dec_gemv_set_waves_override(nw_override);
-    hipEvent_t e0, e1;
-    WM_HIP(hipEventCreate(&e0));
-    WM_HIP(hipEventCreate(&e1));
-    int rc = WM_OK;
-    // capture the launch chain once, replay it: per-kernel time = true serialized duration
-    hipGraph_t g = nullptr;
-    hipGraphExec_t ge = nullptr;
-    WM_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < iters && rc == WM_OK; ++i) {
-        a.W = (const bf16_t *)dW + (size_t)(i % n_mats) * Npad * K;
-        rc = wm_dec_gemv(ctx, a);
-    }
-    WM_HIP(hipStreamEndCapture(s, &g));
-    if (rc == WM_OK) {
-        WM_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        WM_HIP(hipGraphLaunch(ge, s));
-        WM_HIP(hipStreamSynchronize(s));
-        WM_HIP(hipEventRecord(e0, s));
-        WM_HIP(hipGraphLaunch(ge, s));
-    }
-    wm_dec_gemv_set_waves_override(0);
-    WM_HIP(hipEventRecord(e1, s));
-    WM_HIP(hipStreamSynchronize(s));
-    float ms = 0.f;
-    WM_HIP(hipEventElapsedTime(&ms, e0, e1));
-    *avg_us = ms * 1e3f / iters;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (ge) (void)hipGraphExecDestroy(ge);
-    if (g) (void)hipGraphDestroy(g);
-    void *fr[] = {dW, dx, dx16, dg, db, dout, dstat};
-    for (void *p : fr) (void)hipFree(p);
-    return rc;
-}
-
-extern "C" int wmdbg_bench_dec_attention(wm_ctx *ctx, int B, int H, int T, int n_keys, int nsplit, int n_slices,
-                                         int iters, float *avg_us) {
-    WM_TRY(wm_ctx_make_current(ctx));
-    hipStream_t s = ctx->stream;
-    const size_t slice = (size_t)B * H * T * 64;
-    void *dk, *dv, *dq, *dp, *datt;
-    WM_TRY(up(&dk, nullptr, slice * n_slices * 2, s));
-    WM_TRY(up(&dv, nullptr, slice * n_slices * 2, s));
-    WM_TRY(up(&dq, nullptr, (size_t)B * H * 64 * 4, s));
-    WM_TRY(up(&dp, nullptr, (size_t)B * H * 8 * 66 * 4, s));
-    WM_TRY(up(&datt, nullptr, (size_t)B * H * 64 * 2, s));
-    hipEvent_t e0, e1;
-    WM_HIP(hipEventCreate(&e0));
-    WM_HIP(hipEventCreate(&e1));
-    int rc = WM_OK;
-    for (int pass = 0; pass < 2 && rc == WM_OK; ++pass) {
-        if (pass == 1) WM_HIP(hipEventRecord(e0, s));
-        for (int i = 0; i < iters && rc == WM_OK; ++i)
-            rc = wm_dec_attention(ctx, (const float *)dq, (const bf16_t *)dk + (size_t)(i % n_slices) * slice,
-                                  (const bf16_t *)dv + (size_t)(i % n_slices) * slice, B, H, T, n_keys, nullptr, nsplit,
-                                  (float *)dp, (bf16_t *)datt, true);
-    }
-    WM_HIP(hipEventRecord(e1, s));
-    WM_HIP(hipStreamSynchronize(s));
-    float ms = 0.f;
-    WM_HIP(hipEventElapsedTime(&ms, e0, e1));
-    *avg_us = ms * 1e3f / iters;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    void *fr[] = {dk, dv, dq, dp, datt};
-    for (void *p : fr) (void)hipFree(p);
-    return rc;
-}
-
-int wm_launch_trivial(wm_ctx *ctx, int *p, int grid);
-// Dependent-launch floor of this machine: `iters` trivial kernels (each increments one HBM word,
-// so they are truly serialised), eager stream launches vs one captured hipGraph replayed.
-extern "C" int wmdbg_bench_launch_floor(wm_ctx *ctx, int iters, int grid, float *eager_us, float *graph_us) {
-    WM_TRY(wm_ctx_make_current(ctx));
-    hipStream_t s = ctx->stream;
-    void *d;
-    WM_TRY(up(&d, nullptr, 64, s));
-    hipEvent_t e0, e1;
-    WM_HIP(hipEventCreate(&e0));
-    WM_HIP(hipEventCreate(&e1));
-    for (int i = 0; i < 20; ++i) WM_TRY(wm_launch_trivial(ctx, (int *)d, grid));
-    WM_HIP(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) WM_TRY(wm_launch_trivial(ctx, (int *)d, grid));
-    WM_HIP(hipEventRecord(e1, s));
-    WM_HIP(hipStreamSynchronize(s));
-    float ms = 0.f;
-    WM_HIP(hipEventElapsedTime(&ms, e0, e1));
-    *eager_us = ms * 1e3f / iters;
-    hipGraph_t g;
-    hipGraphExec_t ge;
-    WM_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    for (int i = 0; i < iters; ++i) (void)wm_launch_trivial(ctx, (int *)d, grid);
-    WM_HIP(hipStreamEndCapture(s, &g));
-    WM_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-    WM_HIP(hipGraphLaunch(ge, s));
-    WM_HIP(hipStreamSynchronize(s));
-    WM_HIP(hipEventRecord(e0, s));
-    WM_HIP(hipGraphLaunch(ge, s));
-    WM_HIP(hipEventRecord(e1, s));
-    WM_HIP(hipStreamSynchronize(s));
-    WM_HIP(hipEventElapsedTime(&ms, e0, e1));
-    *graph_us = ms * 1e3f / iters;
-    (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
-    return WM_OK;
-}
-
-// Mean duration (us) of `iters` back-to-back launches of one encoder GEMM shape.  Operands as in the encoder:
-// A ~ N(0,1), W ~ N(0, 0.02^2), bias ~ 0.01 N(0,1); the launches rotate over `n_w` weight matrices so that W comes
-// from HBM as it does in the 32-layer encoder (n_w = 1: W stays cache-resident).
-extern "C" int wmdbg_bench_gemm(wm_ctx *ctx, int M, int N, int K, int epi, int iters, int n_w, float *us) {
-    WM_TRY(wm_ctx_make_current(ctx));
-    WM_REQUIRE(epi == EPI_F32 || epi == EPI_BIAS_BF16 || epi == EPI_GELU_BF16 || epi == EPI_RESID_F32, WM_ERR_INVALID,
-               "wmdbg_bench_gemm: epilogue %d not exposed", epi);
-    WM_REQUIRE(n_w >= 1 && n_w <= 64, WM_ERR_INVALID, "wmdbg_bench_gemm: n_w out of range");
-    hipStream_t s = ctx->stream;
-    std::vector<bf16_t> a16((size_t)M * K), w16((size_t)N * K);
-    uint32_t x = 12345u;
-    auto gauss = [&]() {  // Irwin-Hall(4), unit variance
-        float acc = 0.f;
-        for (int i = 0; i < 4; ++i) { x = x * 1664525u + 1013904223u; acc += (float)(x >> 8) * (1.0f / 16777216.0f); }
-        return (acc - 2.0f) * 1.7320508f;
-    };
-    auto f2bf = [](float f) {
-        uint32_t u;
-        memcpy(&u, &f, 4);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return (bf16_t)(u >> 16);
-    };
-    for (auto &v : a16) v = f2bf(gauss());
-    for (auto &v : w16) v = f2bf(0.02f * gauss());
-    std::vector<float> bias(N);
-    for (auto &v : bias) v = 0.01f * gauss();
-    void *dA, *dB, *dC;
-    std::vector<void *> dW(n_w, nullptr);
-    WM_TRY(up(&dA, a16.data(), a16.size() * 2, s));
-    for (int i = 0; i < n_w; ++i) WM_TRY(up(&dW[i], w16.data(), w16.size() * 2, s));
-    WM_TRY(up(&dB, bias.data(), (size_t)N * 4, s));
-    WM_TRY(up(&dC, nullptr, (size_t)M * N * 4, s));
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.A = (const bf16_t *)dA; g.a_rpb = (long)M + 1; g.a_rstride = K;
-    g.bias = (const float *)dB; g.C = dC;
-    g.c_rpb = (long)M + 1; g.c_rstride = N; g.M = M; g.N = N; g.K = K; g.epi = epi;
-    hipEvent_t e0, e1;
-    WM_HIP(hipEventCreate(&e0));
-    WM_HIP(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) { g.W = (const bf16_t *)dW[i % n_w]; WM_TRY(wm_gemm(ctx, g)); }
-    WM_HIP(hipEventRecord(e0, s));
-    for (int i = 0; i < iters; ++i) { g.W = (const bf16_t *)dW[i % n_w]; WM_TRY(wm_gemm(ctx, g)); }
-    WM_HIP(hipEventRecord(e1, s));
-    WM_HIP(hipStreamSynchronize(s));
-    float ms = 0.f;
-    WM_HIP(hipEventElapsedTime(&ms, e0, e1));
-    *us = ms * 1e3f / iters;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
-    for (void *w : dW) (void)hipFree(w);
-    return WM_OK;
-}
-
-int wm_launch_spin(hipStream_t s, int *p, int grid, int cycles);
-// Do two independent branches of a captured hipGraph run concurrently?  Each branch is a chain of
-// `iters` kernels that spin ~`us_each` microseconds on `grid` workgroups.  Returns wall time of one
-// replay with 1 branch and with 2 branches.
-extern "C" int wmdbg_bench_graph_branches(wm_ctx *ctx, int iters, int grid, int us_each, float *one_us, float *two_us) {
-    WM_TRY(wm_ctx_make_current(ctx));
-    hipStream_t s = ctx->stream, s2;
-    WM_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-    void *d;
-    WM_TRY(up(&d, nullptr, 256, s));
-    const int cycles = us_each * 100;  // wall_clock64 ticks at 100 MHz
-    hipEvent_t e0, e1, ef, ej;
-    WM_HIP(hipEventCreate(&e0)); WM_HIP(hipEventCreate(&e1));
-    WM_HIP(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); WM_HIP(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
-    for (int nb = 1; nb <= 2; ++nb) {
-        hipGraph_t g; hipGraphExec_t ge;
-        WM_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        if (nb == 2) { WM_HIP(hipEventRecord(ef, s)); WM_HIP(hipStreamWaitEvent(s2, ef, 0)); }
-        for (int i = 0; i < iters; ++i) {
-            WM_TRY(wm_launch_spin(s, (int *)d, grid, cycles));
-            if (nb == 2) WM_TRY(wm_launch_spin(s2, (int *)d + 16, grid, cycles));
-        }
-        if (nb == 2) { WM_HIP(hipEventRecord(ej, s2)); WM_HIP(hipStreamWaitEvent(s, ej, 0)); }
-        WM_HIP(hipStreamEndCapture(s, &g));
-        WM_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        WM_HIP(hipGraphLaunch(ge, s));
-        WM_HIP(hipStreamSynchronize(s));
-        WM_HIP(hipEventRecord(e0, s));
-        WM_HIP(hipGraphLaunch(ge, s));
-        WM_HIP(hipEventRecord(e1, s));
-        WM_HIP(hipStreamSynchronize(s));
-        float ms = 0.f;
-        WM_HIP(hipEventElapsedTime(&ms, e0, e1));
-        *(nb == 1 ? one_us : two_us) = ms * 1e3f;
-        (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g);
-    }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(ef); (void)hipEventDestroy(ej);
-    (void)hipStreamDestroy(s2); (void)hipFree(d);
     return WM_OK;
 }

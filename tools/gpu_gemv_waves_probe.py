@@ -1,7 +1,7 @@
 import ctypes, sys
 sys.path.insert(0, '.')
 import openai_whisper_coreml_amd as pkg
-c = pkg.binding.Context(); lib = c.lib
+c = pkg.binding.Context(debug=True); lib = c.lib
 us = ctypes.c_float()
 for B in (16, 32, 64):
     for (name, N, K, ln, resid) in [("fc2", 1280, 5120, 0, 1), ("attn_out", 1280, 1280, 0, 1)]:

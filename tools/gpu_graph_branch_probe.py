@@ -1,7 +1,7 @@
 import ctypes, sys
 sys.path.insert(0, '.')
 import openai_whisper_coreml_amd as pkg
-c = pkg.binding.Context(); lib = c.lib
+c = pkg.binding.Context(debug=True); lib = c.lib
 a, b = ctypes.c_float(), ctypes.c_float()
 for grid, us in ((80, 5), (80, 20), (320, 5), (1024, 5)):
     st = lib.wmdbg_bench_graph_branches(c.handle, 100, grid, us, ctypes.byref(a), ctypes.byref(b))

@@ -3,7 +3,7 @@ Per-launch times of each chain alone and together (B = 16, large-v2 shapes)."""
 import ctypes, sys, threading, time
 sys.path.insert(0, '.')
 import openai_whisper_coreml_amd as pkg
-ctxs = [pkg.binding.Context() for _ in range(4)]
+ctxs = [pkg.binding.Context(debug=True) for _ in range(4)]
 lib = ctxs[0].lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 

@@ -2,7 +2,7 @@
 import ctypes, sys, threading
 sys.path.insert(0, '.')
 import openai_whisper_coreml_amd as pkg
-ctxs = [pkg.binding.Context() for _ in range(3)]
+ctxs = [pkg.binding.Context(debug=True) for _ in range(3)]
 lib = ctxs[0].lib
 def attn(c, B, iters=300):
     us = ctypes.c_float()
