@@ -115,7 +115,7 @@ static int ctx_new(int device, wm_ctx **out) {
 
 extern "C" int wm_create_frontend(int device, wm_ctx **out) { return ctx_new(device, out); }
 
-extern "C" int wm_create(const wm_dims *dims, int device, wm_ctx **out) {
+extern "C" int wm_create(const wm_dims *dims, int device, wm_ctx **out) try {
     WM_REQUIRE(dims != nullptr, WM_ERR_INVALID, "null dims");
     WM_TRY(ctx_new(device, out));
     int st = wm_model_create(*out, dims);
@@ -124,9 +124,9 @@ extern "C" int wm_create(const wm_dims *dims, int device, wm_ctx **out) {
         *out = nullptr;
     }
     return st;
-}
+} WM_API_CATCH
 
-extern "C" int wm_clone(wm_ctx *parent, wm_ctx **out) {
+extern "C" int wm_clone(wm_ctx *parent, wm_ctx **out) try {
     WM_REQUIRE(parent && out, WM_ERR_INVALID, "null pointer");
     WM_REQUIRE(parent->model, WM_ERR_STATE, "clone: the parent context has no model");
     WM_TRY(ctx_new(parent->device, out));
@@ -136,7 +136,7 @@ extern "C" int wm_clone(wm_ctx *parent, wm_ctx **out) {
         *out = nullptr;
     }
     return st;
-}
+} WM_API_CATCH
 
 extern "C" void wm_destroy(wm_ctx *ctx) {
     if (!ctx) return;
@@ -152,52 +152,52 @@ extern "C" void wm_destroy(wm_ctx *ctx) {
 }
 
 // ---------------------------------------------------------------- device helpers -----
-extern "C" int wm_dev_malloc(wm_ctx *ctx, size_t bytes, void **dptr) {
+extern "C" int wm_dev_malloc(wm_ctx *ctx, size_t bytes, void **dptr) try {
     WM_TRY(wm_ctx_make_current(ctx));
     WM_REQUIRE(dptr != nullptr, WM_ERR_INVALID, "null dptr");
     WM_HIP(hipMalloc(dptr, bytes ? bytes : 1));
     return WM_OK;
-}
-extern "C" int wm_dev_free(wm_ctx *ctx, void *dptr) {
+} WM_API_CATCH
+extern "C" int wm_dev_free(wm_ctx *ctx, void *dptr) try {
     WM_TRY(wm_ctx_make_current(ctx));
     WM_HIP(hipStreamSynchronize(ctx->stream));
     if (dptr) WM_HIP(hipFree(dptr));
     return WM_OK;
-}
-extern "C" int wm_dev_upload(wm_ctx *ctx, void *dptr, const void *host, size_t bytes) {
+} WM_API_CATCH
+extern "C" int wm_dev_upload(wm_ctx *ctx, void *dptr, const void *host, size_t bytes) try {
     WM_TRY(wm_ctx_make_current(ctx));
     WM_REQUIRE(dptr && host, WM_ERR_INVALID, "null pointer");
     WM_HIP(hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));
     return WM_OK;
-}
-extern "C" int wm_dev_download(wm_ctx *ctx, void *host, const void *dptr, size_t bytes) {
+} WM_API_CATCH
+extern "C" int wm_dev_download(wm_ctx *ctx, void *host, const void *dptr, size_t bytes) try {
     WM_TRY(wm_ctx_make_current(ctx));
     WM_REQUIRE(dptr && host, WM_ERR_INVALID, "null pointer");
     WM_HIP(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));
     return WM_OK;
-}
-extern "C" int wm_sync(wm_ctx *ctx) {
+} WM_API_CATCH
+extern "C" int wm_sync(wm_ctx *ctx) try {
     WM_TRY(wm_ctx_make_current(ctx));
     WM_HIP(hipStreamSynchronize(ctx->stream));
     return WM_OK;
-}
+} WM_API_CATCH
 
 // ---------------------------------------------------------------- profiling ABI ------
-extern "C" int wm_profile_enable(wm_ctx *ctx, int on) {
+extern "C" int wm_profile_enable(wm_ctx *ctx, int on) try {
     WM_TRY(wm_ctx_make_current(ctx));
     ctx->prof.drain();
     ctx->prof.on = (on != 0);
     return WM_OK;
-}
-extern "C" int wm_profile_reset(wm_ctx *ctx) {
+} WM_API_CATCH
+extern "C" int wm_profile_reset(wm_ctx *ctx) try {
     WM_TRY(wm_ctx_make_current(ctx));
     WM_HIP(hipStreamSynchronize(ctx->stream));
     ctx->prof.reset();
     return WM_OK;
-}
-extern "C" int wm_profile_json(wm_ctx *ctx, char *buf, size_t n) {
+} WM_API_CATCH
+extern "C" int wm_profile_json(wm_ctx *ctx, char *buf, size_t n) try {
     WM_TRY(wm_ctx_make_current(ctx));
     WM_REQUIRE(buf && n > 2, WM_ERR_INVALID, "bad buffer");
     WM_HIP(hipStreamSynchronize(ctx->stream));
@@ -215,13 +215,13 @@ extern "C" int wm_profile_json(wm_ctx *ctx, char *buf, size_t n) {
     WM_REQUIRE(s.size() + 1 <= n, WM_ERR_INVALID, "buffer too small (%zu needed)", s.size() + 1);
     memcpy(buf, s.c_str(), s.size() + 1);
     return WM_OK;
-}
+} WM_API_CATCH
 // Cost of the measurement itself.  A kernel that spins for exactly T microseconds of the device
 // clock is bracketed by the same two hipEventRecord calls the profiler uses, queued behind a long
 // kernel so that the host runs ahead of the GPU (as it does in the real pipeline); the bias is the
 // mean (elapsed - T): launch latency of a dependent kernel plus the completion of the closing event.
 int wm_launch_spin(hipStream_t s, int *p, int grid, int cycles);
-extern "C" int wm_profile_overhead_us(wm_ctx *ctx, float *us) {
+extern "C" int wm_profile_overhead_us(wm_ctx *ctx, float *us) try {
     WM_TRY(wm_ctx_make_current(ctx));
     WM_REQUIRE(us, WM_ERR_INVALID, "null pointer");
     WM_HIP(hipStreamSynchronize(ctx->stream));
@@ -244,12 +244,12 @@ extern "C" int wm_profile_overhead_us(wm_ctx *ctx, float *us) {
     for (auto &e : ev) (void)hipEventDestroy(e);
     *us = (float)(tot * 1e3 / n) - (float)spin_us;
     return WM_OK;
-}
-extern "C" int wm_last_stage_ms(wm_ctx *ctx, float out3[3]) {
+} WM_API_CATCH
+extern "C" int wm_last_stage_ms(wm_ctx *ctx, float out3[3]) try {
     WM_REQUIRE(ctx && out3, WM_ERR_INVALID, "null pointer");
     for (int i = 0; i < 3; ++i) out3[i] = ctx->stage_ms[i];
     return WM_OK;
-}
+} WM_API_CATCH
 
 // ---------------------------------------------------------------- boundary #1 --------
 static int ensure_scratch(wm_ctx *ctx, size_t bytes) {
@@ -273,7 +273,7 @@ static size_t dtype_size(wm_dtype t) {
 }
 
 extern "C" int wm_logmel(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int n_chunks,
-                         int n_mels, void *out, wm_dtype out_dtype, wm_mem mem) {
+                         int n_mels, void *out, wm_dtype out_dtype, wm_mem mem) try {
     WM_TRY(wm_ctx_make_current(ctx));
     WM_REQUIRE(n_chunks >= 0, WM_ERR_INVALID, "n_chunks < 0");
     WM_REQUIRE(n_mels == 80 || n_mels == 128, WM_ERR_INVALID, "n_mels must be 80 or 128, got %d", n_mels);
@@ -297,7 +297,7 @@ extern "C" int wm_logmel(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int n
     WM_HIP(hipMemcpyAsync(out, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));
     return WM_OK;
-}
+} WM_API_CATCH
 
 // The reference's symbol (bridge.h:11 / lib.rs:110-122).  One lazily created context per
 // process, serialised by a mutex so the symbol stays re-entrant like the reference's.

@@ -204,7 +204,7 @@ extern "C" int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, co
 }
 
 // Single-query attention: q f32 [B][H*64], k/v f32 [B][H][T][64] (rounded to bf16), first
-// n_keys positions, `nsplit` flash-decoding splits; out f32 [B][H*64] (partials combined on host).
+// n_keys positions; `nsplit` (1, 2, 4, 8) workgroups share the 8 streams of a pair; out f32 [B][H*64].
 extern "C" int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, const float *v, int B, int H, int T,
                                    int n_keys, int nsplit, float *out) {
     WM_TRY(wm_ctx_make_current(ctx));
@@ -216,7 +216,7 @@ extern "C" int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, 
     WM_TRY(up(&dq, q, (size_t)B * H * 64 * 4, s));
     WM_TRY(up(&dk, k16.data(), k16.size() * 2, s));
     WM_TRY(up(&dv, v16.data(), v16.size() * 2, s));
-    WM_TRY(up(&dp, nullptr, (size_t)B * H * (nsplit > 0 ? nsplit : 1) * 66 * 4, s));
+    WM_TRY(up(&dp, nullptr, (size_t)B * H * WM_MAXSPLIT * 66 * 4, s));
     void *datt;
     WM_TRY(up(&datt, nullptr, (size_t)B * H * 64 * 2, s));
     // nsplit == 0 selects the decoder's self-attention kernel (one 4-wave workgroup per pair), nsplit == -1 the
@@ -305,7 +305,7 @@ extern "C" int wmdbg_bench_dec_attention(wm_ctx *ctx, int B, int H, int T, int n
     WM_TRY(up(&dk, nullptr, slice * n_slices * 2, s));
     WM_TRY(up(&dv, nullptr, slice * n_slices * 2, s));
     WM_TRY(up(&dq, nullptr, (size_t)B * H * 64 * 4, s));
-    WM_TRY(up(&dp, nullptr, (size_t)B * H * 8 * 66 * 4, s));
+    WM_TRY(up(&dp, nullptr, (size_t)B * H * WM_MAXSPLIT * 66 * 4, s));
     WM_TRY(up(&datt, nullptr, (size_t)B * H * 64 * 2, s));
     hipEvent_t e0, e1;
     WM_HIP(hipEventCreate(&e0));

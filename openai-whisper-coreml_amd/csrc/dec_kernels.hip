@@ -68,7 +68,8 @@ struct DecGemvDev {
     int n_ctx, n_head;
     long ldo;
     unsigned long long *tilemax;  // [B][n_tiles] (DE_LOGITS)
-    int n_tiles, n_tiles_pad;     // n_tiles_pad: n_tiles rounded up to 8 when a tile is shared by several workgroups
+    int n_tiles;                  // 16-row weight tiles
+    int n_tg, n_tg_pad;           // tile groups (TN tiles each); n_tg_pad: rounded up to 8 when a group is shared by several workgroups
     int arg_first, arg_last;
     const unsigned *mask;  // DE_LOGITS: suppressed-token bitmaps [2][mask_words] or null
     int mask_words, mask_first_pos;
@@ -76,7 +77,7 @@ struct DecGemvDev {
     const char *pf_ptr;    // next GEMV's weights: extra workgroups pull them into this XCD's L2
     long pf_tile_bytes;    // bytes of one 16-row weight tile of that matrix
     int pf_tiles;
-    int bgroups;           // workgroups per weight tile: group g takes the 16-row batch blocks g, g + bgroups, ...
+    int bgroups;           // workgroups per tile group along the batch: group g takes batch rows [g, g + 1) * NBLK * 16
 };
 
 // L2 warm-up workgroup: blockIdx >= n_tiles of the compute grid.  Workgroup n_tiles + t reads tile t of
@@ -100,237 +101,299 @@ __device__ __forceinline__ void l2_warm_tile(const char *base, long tile_bytes, 
 }
 
 // The decode GEMV (round 2): out[b][n] = sum_k a[b][k] W[n][k] for a decode group of any size.
-//   * one workgroup per 16-row weight tile; its NW waves split K (SPW k-steps of 32 each -- the split depends on K
-//     only, never on the batch, so a row's sum is formed in the same order whatever group it is decoded in);
-//   * every weight load is issued first (10-40 KiB per workgroup in flight), then the activation fragments of the
-//     first batch block: bf16 rows straight from L2 in MFMA A-operand order -- no LDS staging, no prologue;
+//   * a workgroup owns TN adjacent 16-row weight tiles and NBLK blocks of 16 batch rows; its NW waves split K (SPW
+//     k-steps of 32 each -- the split depends on K only, never on the batch or on TN / NBLK, so a row's sum is formed in
+//     the same order whatever group it is decoded in and however the launch is shaped);
+//   * EVERYTHING the workgroup needs is requested up front -- weights (TN x SPW KiB per wave), the bf16 activation
+//     fragments of all its batch blocks straight from L2 in MFMA A-operand order, and the epilogue operands -- so the
+//     kernel has ONE memory round trip on its critical path whatever the batch; large batches are covered by more
+//     workgroups per tile group (bgroups) and wider tile groups (TN: an activation fragment feeds TN products, which
+//     divides the L2 -> CU traffic of the activations), never by a serial loop;
 //   * LayerNorm is FOLDED: gamma lives in the weights (W' = W g), so the product runs on the raw bf16 residual and the
 //     row statistics enter in the epilogue, out = rstd (a W'^T - mean c1) + c2 -- they arrive as deterministic per-tile
 //     partial sums of the f32 residual from whoever wrote it last and are off the critical path;
-//   * batches above 16 rows: blocks of 16 looped INSIDE the workgroup with the weights held in registers and the next
-//     block's fragments requested before this block's reduction (bgroups workgroups share a tile at large batches);
-//   * cross-wave (split-K) sums through a double-buffered LDS slab in wave order, one barrier per block; wave 0 runs the
-//     fused epilogue: bias / GELU / residual (+ bf16 copy + partial statistics) / KV append / arg-max (+ suppress
-//     bitmaps, timestamp rules).
-// LDS carve (dynamic): red [2][NW][64][4] f32 | st [16][2] f32
-template <int SPW, int EPI, bool LN>
-__global__ __launch_bounds__(LN || SPW == 12 ? 512 : 1024) void dec_gemv_kernel(DecGemvDev p) {
+//   * cross-wave (split-K) sums through LDS in wave order, one barrier; the TN x NBLK (tile, block) units are spread
+//     over the waves for the fused epilogue: bias / GELU / residual (+ bf16 copy + partial statistics) / KV append /
+//     arg-max (+ suppress bitmaps, timestamp rules).
+// LDS carve (dynamic): red [NW][TN*NBLK][64][4] f32 | st [NW][16][2] f32
+template <int EPI, bool LN>
+struct GemvUnitOps {
+    float c1v, c2v;
+    float xold[4];
+    int4 trng[4];
+    float2 sv[LN ? 20 : 1];  // statistics parts per lane group: d/16 <= 80 parts
+};
+
+template <int EPI, bool LN>
+__device__ __forceinline__ void gemv_unit_load(const DecGemvDev &p, GemvUnitOps<EPI, LN> &o, int tile, int b0, int lane) {
+    const int nrow = lane & 15, kq = lane >> 4;
+    const int n = tile * 16 + nrow;
+    const int nc = n < p.N ? n : p.N - 1;
+    const int nb = p.B - b0 < 16 ? p.B - b0 : 16;
+    o.c1v = 0.f;
+    o.c2v = p.c2 ? p.c2[nc] : 0.f;
+    if (LN) o.c1v = p.c1[nc];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        o.xold[r] = 0.f;
+        o.trng[r] = make_int4(0, 0, 0, 0);
+    }
+    if (EPI == DE_RESID) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int bl = kq * 4 + r;
+            o.xold[r] = p.out_f32[(long)(b0 + (bl < nb ? bl : nb - 1)) * p.ldo + nc];
+        }
+    }
+    if (EPI == DE_LOGITS && p.ts.rng) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int bl = kq * 4 + r;
+            o.trng[r] = *(const int4 *)(p.ts.rng + (long)(b0 + (bl < nb ? bl : nb - 1)) * 4);
+        }
+    }
+    if (LN) {
+        // all K/16 parts of the block are valid (the embedding kernels zero the ones they do not write), K/16 is a
+        // multiple of 4: every lane group reads K/64 of them, a wave-uniform count
+        const float *sp = p.stats_in + (long)(b0 >> 4) * p.stats_stride + (kq * 16 + nrow) * 2;
+        const int nu = p.K >> 6;
+#pragma unroll
+        for (int u = 0; u < 20; ++u) {
+            o.sv[u] = make_float2(0.f, 0.f);
+            if (u < nu) o.sv[u] = *(const float2 *)(sp + u * 128);
+        }
+    }
+}
+
+// rstd / -mean rstd of the unit's 16 rows from the partial sums -> wave-private LDS (st), so that every lane can read
+// the four rows its accumulator registers hold.  The partial sums were written in a FIXED slab order by the producer
+// of the residual, so this sum is deterministic and needs no atomics.
+template <int EPI, bool LN>
+__device__ __forceinline__ void gemv_unit_stats(const DecGemvDev &p, const GemvUnitOps<EPI, LN> &o, float *st, int lane) {
+    if (!LN) return;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < 20; ++u) {
+        s1 += o.sv[u].x;
+        s2 += o.sv[u].y;
+    }
+    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+    const float mean = s1 / (float)p.K;
+    float var = s2 / (float)p.K - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float rstd = rsqrtf(var + 1e-5f);
+    if (lane < 16) *(float2 *)(st + lane * 2) = make_float2(rstd, -mean * rstd);
+}
+
+// epilogue of one (tile, block) unit by one wave: D col n = lane & 15, rows b = b0 + kq*4 + r
+template <int EPI, bool LN>
+__device__ __forceinline__ void gemv_unit_epilogue(const DecGemvDev &p, const GemvUnitOps<EPI, LN> &o, const f32x4 acc,
+                                                   const float *st, int tile, int b0, int lane, int pos, unsigned mword0,
+                                                   unsigned mword1) {
+    const int nrow = lane & 15, kq = lane >> 4;
+    const int n0 = tile * 16, n = n0 + nrow;
+    const bool nvalid = n < p.N;
+    const int nb = p.B - b0 < 16 ? p.B - b0 : 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int bl = kq * 4 + r;
+        const int b = b0 + bl;
+        const bool bvalid = bl < nb;
+        float v;
+        if (LN) {
+            const float2 ms = *(const float2 *)(st + bl * 2);
+            v = __fmaf_rn(ms.x, acc[r], __fmaf_rn(ms.y, o.c1v, o.c2v));  // rstd (acc - mean c1) + c2
+        } else {
+            v = acc[r] + o.c2v;
+        }
+        if (EPI == DE_LOGITS && p.ts.rng) {
+            // timestamp rules: best allowed text token, best allowed timestamp, and the (max, sum exp) partial of the
+            // allowed timestamps of this tile (only tiles that reach into the timestamp range carry the last two)
+            const unsigned mw = (pos == p.mask_first_pos) ? mword1 : mword0;
+            const bool ok = bvalid && nvalid && !((mw >> (n & 31)) & 1u);
+            const bool in_text = ok && n >= o.trng[r].x && n < o.trng[r].y;
+            const bool in_ts = ok && n >= o.trng[r].z && n < o.trng[r].w;
+            unsigned long long kt = in_text ? argmax_key(v, n) : 0ull, ks = in_ts ? argmax_key(v, n) : 0ull;
+#pragma unroll
+            for (int q = 1; q < 16; q <<= 1) {
+                const unsigned long long a = __shfl_xor(kt, q), c = __shfl_xor(ks, q);
+                kt = a > kt ? a : kt;
+                ks = c > ks ? c : ks;
+            }
+            if (bvalid && nrow == 0) p.tilemax[(long)b * p.n_tiles + tile] = kt;
+            if (n0 + 16 > p.ts.ts_begin) {  // wave-uniform
+                float mx = in_ts ? v : -1e30f;
+#pragma unroll
+                for (int q = 1; q < 16; q <<= 1) mx = fmaxf(mx, __shfl_xor(mx, q));
+                float se = in_ts ? __expf(v - mx) : 0.f;
+#pragma unroll
+                for (int q = 1; q < 16; q <<= 1) se += __shfl_xor(se, q);
+                if (bvalid && nrow == 0) {
+                    p.ts.key_ts[(long)b * p.n_tiles + tile] = ks;
+                    *(float2 *)(p.ts.lse + ((long)b * p.n_tiles + tile) * 2) = make_float2(mx, se);
+                }
+            }
+            if (bvalid && nvalid && p.out_f32) p.out_f32[(long)b * p.ldo + n] = v;
+            continue;
+        }
+        if (EPI == DE_LOGITS) {
+            // arg-max over [arg_first, arg_last], first maximal index wins (Whisper.swift:38)
+            unsigned long long key = 0ull;
+            const unsigned mw = (pos == p.mask_first_pos) ? mword1 : mword0;  // zero when no filter is set
+            if (bvalid && nvalid && n >= p.arg_first && n <= p.arg_last && !((mw >> (n & 31)) & 1u)) key = argmax_key(v, n);
+#pragma unroll
+            for (int q = 1; q < 16; q <<= 1) {
+                const unsigned long long ok = __shfl_xor(key, q);
+                key = ok > key ? ok : key;
+            }
+            if (bvalid && nrow == 0) p.tilemax[(long)b * p.n_tiles + tile] = key;
+            if (bvalid && nvalid && p.out_f32) p.out_f32[(long)b * p.ldo + n] = v;
+            continue;
+        }
+        if (EPI == DE_RESID) {
+            // residual update (f32 + the bf16 copy the next GEMV multiplies) + this tile's partial LayerNorm
+            // statistics of the updated rows
+            float xn = 0.f;
+            if (bvalid && nvalid) {
+                xn = o.xold[r] + v;
+                p.out_f32[(long)b * p.ldo + n] = xn;
+                if (p.out_bf16) p.out_bf16[(long)b * p.ldo + n] = f2bf(xn);
+            }
+            float s1 = xn, s2 = xn * xn;
+#pragma unroll
+            for (int q = 1; q < 16; q <<= 1) {
+                s1 += __shfl_xor(s1, q);
+                s2 += __shfl_xor(s2, q);
+            }
+            if (p.stats_out && nrow == 0)
+                *(float2 *)(p.stats_out + (long)(b0 >> 4) * p.stats_stride + ((long)tile * 16 + bl) * 2) = make_float2(s1, s2);
+            continue;
+        }
+        if (!bvalid || !nvalid) continue;
+        if (EPI == DE_QKV) {
+            const int d = p.N / 3;
+            if (n < d) {
+                p.out_f32[(long)b * d + n] = v;
+            } else {
+                const int hn = (n < 2 * d) ? n - d : n - 2 * d;
+                bf16_t *c = (n < 2 * d) ? p.kcache : p.vcache;
+                c[((long)(b * p.n_head + (hn >> 6)) * p.n_ctx + pos) * 64 + (hn & 63)] = f2bf(v);
+            }
+        } else if (EPI == DE_Q) {
+            p.out_f32[(long)b * p.ldo + n] = v;
+        } else if (EPI == DE_GELU) {
+            p.out_bf16[(long)b * p.ldo + n] = f2bf(gelu_erf(v));
+        }
+    }
+}
+
+template <int SPW, int TN, int NBLK, int EPI, bool LN>
+__global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1) ? 512 : 1024) void dec_gemv_kernel(DecGemvDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NU = TN * NBLK;
     const int NW = blockDim.x >> 6;
-    // Workgroup id -> (tile, group): ids 8q .. 8q+7 are tiles 8(q / G) .. +7 of group q % G, so the workgroups of a tile
-    // are dispatched back to back AND on the same XCD (id % 8): the later ones read the weights from the L2 the first
-    // one filled -- one HBM stream per tile.  (G == 1: id == tile.)
+    // Workgroup id -> (tile group, batch group): ids 8q .. 8q+7 are tile groups 8(q / G) .. +7 of batch group q % G, so
+    // the workgroups of a tile group are dispatched back to back AND on the same XCD (id % 8): the later ones read the
+    // weights from the L2 the first one filled -- one HBM stream per tile.  (G == 1: id == tile group.)
     const int G = p.bgroups;
     const int wg = blockIdx.x;
     const int q = wg >> 3;
-    const int tile = (q / G) * 8 + (wg & 7);
+    const int tg = (q / G) * 8 + (wg & 7);
     const int grp = q % G;
-    if (wg >= p.n_tiles_pad * G || tile >= p.n_tiles) {  // workgroup-uniform: warm-up workgroups and row padding
-        const int t = wg - p.n_tiles_pad * G;
+    if (wg >= p.n_tg_pad * G || tg >= p.n_tg) {  // workgroup-uniform: warm-up workgroups and padding
+        const int t = wg - p.n_tg_pad * G;
         if (t >= 0 && t < p.pf_tiles) l2_warm_tile(p.pf_ptr, p.pf_tile_bytes, t, NW * 64);
         return;
     }
     float *red = (float *)smem;
-    float *st = red + 2 * NW * 256;
+    float *st = red + NW * NU * 256 + (threadIdx.x >> 6) * 32;  // wave-private
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrow = lane & 15, kq = lane >> 4;
-    const int n0 = tile * 16;
-    // fragment-tiled weights (WL_TILED): k-step s of n-tile t is the contiguous KiB at
-    // ((t * K/32 + s) * 64 + lane) * 8 -- one perfectly coalesced dwordx4 per lane per step
-    const bf16_t *wp = p.W + (((long)tile * (p.K >> 5) + (long)wave * SPW) * 64 + lane) * 8;
-    u32x4 wf[SPW];
+    const int tile0 = tg * TN;
+    const int bb = grp * NBLK * 16;  // first batch row of this workgroup (< B by construction of the grid)
+
+    // ---- 1. every load of the workgroup in flight: weights (fragment-tiled: k-step s of n-tile t is the contiguous
+    // KiB at ((t * K/32 + s) * 64 + lane) * 8 -- one perfectly coalesced dwordx4 per lane per step) ...
+    u32x4 wf[TN][SPW];
 #pragma unroll
-    for (int u = 0; u < SPW; ++u) wf[u] = __builtin_nontemporal_load((const u32x4 *)(wp + u * 512));
-    const int kbase = wave * SPW * 32 + kq * 8;
-    u32x4 af[SPW];
-    int b0 = grp * 16;
-    {
-        const int rb = b0 + nrow;
-        const bf16_t *ap = p.a + (long)(rb < p.B ? rb : p.B - 1) * p.K + kbase;  // clamped row: unconditional loads
+    for (int t = 0; t < TN; ++t) {
+        const int tc = tile0 + t < p.n_tiles ? tile0 + t : p.n_tiles - 1;  // clamped: unconditional loads
+        const bf16_t *wp = p.W + (((long)tc * (p.K >> 5) + (long)wave * SPW) * 64 + lane) * 8;
 #pragma unroll
-        for (int u = 0; u < SPW; ++u) af[u] = *(const u32x4 *)(ap + u * 32);
+        for (int u = 0; u < SPW; ++u) wf[t][u] = __builtin_nontemporal_load((const u32x4 *)(wp + u * 512));
     }
-    // epilogue operands of wave 0 that do not depend on the batch block
-    const int n = n0 + nrow;
-    const bool nvalid = n < p.N;
-    const int nc = nvalid ? n : p.N - 1;
-    float c1v = 0.f, c2v = 0.f;
+    // ... the activation fragments of its batch blocks ...
+    const int kbase = wave * SPW * 32 + kq * 8;
+    u32x4 af[NBLK][SPW];
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) {
+        const int rb = bb + j * 16 + nrow;
+        const bf16_t *ap = p.a + (long)(rb < p.B ? rb : p.B - 1) * p.K + kbase;  // clamped row
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) af[j][u] = *(const u32x4 *)(ap + u * 32);
+    }
+    // ... and the epilogue operands of the (tile, block) unit this wave will finish: unit u = j * TN + t -> wave u % NW
     int pos = 0;
     unsigned mword0 = 0u, mword1 = 0u;
-    if (wave == 0) {  // wave-uniform
-        if (p.c2) c2v = p.c2[nc];
-        if (LN) c1v = p.c1[nc];
-        if (p.pos_ptr) pos = *p.pos_ptr;
-        if (EPI == DE_LOGITS && p.mask) {
-            mword0 = p.mask[nc >> 5];
-            mword1 = p.mask[p.mask_words + (nc >> 5)];
-        }
+    GemvUnitOps<EPI, LN> ops;
+    const bool has_unit = wave < NU;  // wave-uniform
+    int utile = tile0, ub0 = bb;
+    if (has_unit) {
+        utile = tile0 + wave % TN;
+        ub0 = bb + (wave / TN) * 16;
+        if (utile >= p.n_tiles) utile = p.n_tiles - 1;
+        if (ub0 >= p.B) ub0 = bb;
+        gemv_unit_load<EPI, LN>(p, ops, utile, ub0, lane);
     }
-    int par = 0;
-    for (; b0 < p.B; b0 += G * 16, par ^= 1) {  // workgroup-uniform trip count
-        const int nb = p.B - b0 < 16 ? p.B - b0 : 16;  // rows of this block
-        // ---- wave 0: this block's epilogue operands, requested before the products
-        float xold[4] = {0.f, 0.f, 0.f, 0.f};
-        int4 trng[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) trng[r] = make_int4(0, 0, 0, 0);
-        constexpr int SP = 20;  // statistics parts per lane group: d/16 <= 80 parts
-        float2 sv[LN ? SP : 1];
-        if (wave == 0) {
-            if (EPI == DE_RESID) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int bl = kq * 4 + r;
-                    xold[r] = p.out_f32[(long)(b0 + (bl < nb ? bl : nb - 1)) * p.ldo + nc];
-                }
-            }
-            if (EPI == DE_LOGITS && p.ts.rng) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int bl = kq * 4 + r;
-                    trng[r] = *(const int4 *)(p.ts.rng + (long)(b0 + (bl < nb ? bl : nb - 1)) * 4);
-                }
-            }
-            if (LN) {
-                // all K/16 parts of the block are valid (the embedding kernels zero the ones they do not write), K/16 is
-                // a multiple of 4: every lane group reads K/64 of them, a wave-uniform count
-                const float *sp = p.stats_in + (long)(b0 >> 4) * p.stats_stride + (kq * 16 + nrow) * 2;
-                const int nu = p.K >> 6;
-#pragma unroll
-                for (int u = 0; u < SP; ++u) {
-                    sv[u] = make_float2(0.f, 0.f);
-                    if (u < nu) sv[u] = *(const float2 *)(sp + u * 128);
-                }
-            }
-        }
-        // ---- products of this wave's K range
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < SPW; ++u)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[u]),
-                                                          __builtin_bit_cast(bf16x8, wf[u]), acc, 0, 0, 0);
-        // ---- next block's fragments: in flight during the reduction and the epilogue
-        if (b0 + G * 16 < p.B) {
-            const int rb = b0 + G * 16 + nrow;
-            const bf16_t *ap = p.a + (long)(rb < p.B ? rb : p.B - 1) * p.K + kbase;
-#pragma unroll
-            for (int u = 0; u < SPW; ++u) af[u] = *(const u32x4 *)(ap + u * 32);
-        }
-        float *redp = red + par * NW * 256;
-        if (wave != 0) *(f32x4 *)(redp + (wave * 64 + lane) * 4) = acc;
-        if (LN && wave == 0) {
-            // row statistics: the partial sums were written in a FIXED slab order by the producer of the residual, so
-            // this sum is deterministic and needs no atomics; every lane ends with (rstd, -mean rstd) of row lane & 15
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int u = 0; u < SP; ++u) {
-                s1 += sv[u].x;
-                s2 += sv[u].y;
-            }
-            s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
-            s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-            const float mean = s1 / (float)p.K;
-            float var = s2 / (float)p.K - mean * mean;
-            var = var > 0.f ? var : 0.f;
-            const float rstd = rsqrtf(var + 1e-5f);
-            if (lane < 16) *(float2 *)(st + lane * 2) = make_float2(rstd, -mean * rstd);
-        }
-        __syncthreads();
-        if (wave != 0) continue;  // waves 1.. go on to the next block; the LDS slab alternates
-        for (int w = 1; w < NW; ++w) acc += *(const f32x4 *)(redp + (w * 64 + lane) * 4);
+    if (p.pos_ptr) pos = *p.pos_ptr;
+    if (EPI == DE_LOGITS && p.mask && has_unit) {
+        const int n = utile * 16 + nrow;
+        const int nc = n < p.N ? n : p.N - 1;
+        mword0 = p.mask[nc >> 5];
+        mword1 = p.mask[p.mask_words + (nc >> 5)];
+    }
 
-        // ---- epilogue (wave 0): D col n = lane & 15, rows b = b0 + kq*4 + r -------------------
+    // ---- 2. products of this wave's K range: an activation fragment feeds the TN tiles
+    f32x4 acc[NBLK][TN];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int bl = kq * 4 + r;
-            const int b = b0 + bl;
-            const bool bvalid = bl < nb;
-            float v;
-            if (LN) {
-                const float2 ms = *(const float2 *)(st + bl * 2);
-                v = __fmaf_rn(ms.x, acc[r], __fmaf_rn(ms.y, c1v, c2v));  // rstd (acc - mean c1) + c2
-            } else {
-                v = acc[r] + c2v;
-            }
-            if (EPI == DE_LOGITS && p.ts.rng) {
-                // timestamp rules: best allowed text token, best allowed timestamp, and the (max, sum exp) partial of the
-                // allowed timestamps of this tile (only tiles that reach into the timestamp range carry the last two)
-                const unsigned mw = (pos == p.mask_first_pos) ? mword1 : mword0;
-                const bool ok = bvalid && nvalid && !((mw >> (n & 31)) & 1u);
-                const bool in_text = ok && n >= trng[r].x && n < trng[r].y;
-                const bool in_ts = ok && n >= trng[r].z && n < trng[r].w;
-                unsigned long long kt = in_text ? argmax_key(v, n) : 0ull, ks = in_ts ? argmax_key(v, n) : 0ull;
+    for (int j = 0; j < NBLK; ++j)
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    const unsigned long long a = __shfl_xor(kt, o), c = __shfl_xor(ks, o);
-                    kt = a > kt ? a : kt;
-                    ks = c > ks ? c : ks;
-                }
-                if (bvalid && nrow == 0) p.tilemax[(long)b * p.n_tiles + tile] = kt;
-                if (n0 + 16 > p.ts.ts_begin) {  // workgroup-uniform
-                    float mx = in_ts ? v : -1e30f;
+        for (int t = 0; t < TN; ++t) {
+            f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-                    float se = in_ts ? __expf(v - mx) : 0.f;
+            for (int u = 0; u < SPW; ++u)
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[j][u]),
+                                                             __builtin_bit_cast(bf16x8, wf[t][u]), a4, 0, 0, 0);
+            acc[j][t] = a4;
+        }
+    // ---- 3. cross-wave (split-K) reduction through LDS; statistics of this wave's unit meanwhile
+    if (NU > 1 || wave != 0) {  // a single unit is finished by wave 0 from its own registers
 #pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) se += __shfl_xor(se, o);
-                    if (bvalid && nrow == 0) {
-                        p.ts.key_ts[(long)b * p.n_tiles + tile] = ks;
-                        *(float2 *)(p.ts.lse + ((long)b * p.n_tiles + tile) * 2) = make_float2(mx, se);
-                    }
-                }
-                if (bvalid && nvalid && p.out_f32) p.out_f32[(long)b * p.ldo + n] = v;
-                continue;
-            }
-            if (EPI == DE_LOGITS) {
-                // arg-max over [arg_first, arg_last], first maximal index wins (Whisper.swift:38)
-                unsigned long long key = 0ull;
-                const unsigned mw = (pos == p.mask_first_pos) ? mword1 : mword0;  // zero when no filter is set
-                if (bvalid && nvalid && n >= p.arg_first && n <= p.arg_last && !((mw >> (n & 31)) & 1u)) key = argmax_key(v, n);
+        for (int j = 0; j < NBLK; ++j)
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    const unsigned long long ok = __shfl_xor(key, o);
-                    key = ok > key ? ok : key;
-                }
-                if (bvalid && nrow == 0) p.tilemax[(long)b * p.n_tiles + tile] = key;
-                if (bvalid && nvalid && p.out_f32) p.out_f32[(long)b * p.ldo + n] = v;
-                continue;
-            }
-            if (EPI == DE_RESID) {
-                // residual update (f32 + the bf16 copy the next GEMV multiplies) + this tile's partial LayerNorm
-                // statistics of the updated rows
-                float xn = 0.f;
-                if (bvalid && nvalid) {
-                    xn = xold[r] + v;
-                    p.out_f32[(long)b * p.ldo + n] = xn;
-                    if (p.out_bf16) p.out_bf16[(long)b * p.ldo + n] = f2bf(xn);
-                }
-                float s1 = xn, s2 = xn * xn;
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1 += __shfl_xor(s1, o);
-                    s2 += __shfl_xor(s2, o);
-                }
-                if (p.stats_out && nrow == 0)
-                    *(float2 *)(p.stats_out + (long)(b0 >> 4) * p.stats_stride + ((long)tile * 16 + bl) * 2) = make_float2(s1, s2);
-                continue;
-            }
-            if (!bvalid || !nvalid) continue;
-            if (EPI == DE_QKV) {
-                const int d = p.N / 3;
-                if (n < d) {
-                    p.out_f32[(long)b * d + n] = v;
-                } else {
-                    const int hn = (n < 2 * d) ? n - d : n - 2 * d;
-                    bf16_t *c = (n < 2 * d) ? p.kcache : p.vcache;
-                    c[((long)(b * p.n_head + (hn >> 6)) * p.n_ctx + pos) * 64 + (hn & 63)] = f2bf(v);
-                }
-            } else if (EPI == DE_Q) {
-                p.out_f32[(long)b * p.ldo + n] = v;
-            } else if (EPI == DE_GELU) {
-                p.out_bf16[(long)b * p.ldo + n] = f2bf(gelu_erf(v));
+            for (int t = 0; t < TN; ++t) *(f32x4 *)(red + ((wave * NU + j * TN + t) * 64 + lane) * 4) = acc[j][t];
+    }
+    if (has_unit) gemv_unit_stats<EPI, LN>(p, ops, st, lane);
+    __syncthreads();
+    // ---- 4. fused epilogues: unit u on wave u % NW (first unit's operands are already here)
+    for (int u = wave; u < NU; u += NW) {  // wave-uniform
+        const int t = u % TN, j = u / TN;
+        const int tile = tile0 + t, b0 = bb + j * 16;
+        if (tile >= p.n_tiles || b0 >= p.B) continue;
+        if (u != wave) {  // more units than waves (small models): operands fetched late
+            gemv_unit_load<EPI, LN>(p, ops, tile, b0, lane);
+            gemv_unit_stats<EPI, LN>(p, ops, st, lane);
+            if (EPI == DE_LOGITS && p.mask) {
+                const int n = tile * 16 + nrow;
+                const int nc = n < p.N ? n : p.N - 1;
+                mword0 = p.mask[nc >> 5];
+                mword1 = p.mask[p.mask_words + (nc >> 5)];
             }
         }
+        f32x4 sum = NU == 1 ? acc[0][0] : *(const f32x4 *)(red + ((0 * NU + u) * 64 + lane) * 4);
+        for (int w = 1; w < NW; ++w) sum += *(const f32x4 *)(red + ((w * NU + u) * 64 + lane) * 4);
+        gemv_unit_epilogue<EPI, LN>(p, ops, sum, st, tile, b0, lane, pos, mword0, mword1);
     }
 }
 
@@ -407,177 +470,57 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int *__restrict__ 
 }
 
 // ------------------------------------------------------------------ single-query attention
-// grid (B*H, nsplit), 1024 threads = 16 waves.  Keys [start, end) of this split; 8 lanes share
-// one 128-byte K/V row (16 B each), a wave covers 8 rows per load, the 16 waves 128 rows; every
-// lane requests all of its rows up front so a CU streams its (sequence, head) cache slice at HBM
-// rate.  nsplit == 1: writes the normalised head output
-// as bf16 (the out-projection's A operand); nsplit > 1: writes (m, l, o[64]) partials for
-// dec_attn_combine_kernel.
-constexpr int ATT_NW = 16;
+// One kernel serves the decoder's two attentions.  The rows of a (sequence, head) pair are dealt to NS canonical
+// STREAMS (NS = 8 for the cross-attention over the 1500 encoder frames, 4 for the causal self-attention over <= 448
+// cached rows): row i belongs to stream (i / 8) % NS, 8 lanes share a 128-byte K/V row (16 B each), a wave is one
+// stream and walks its rows in blocks of U loads (K and V of a block requested together), keeping its own running
+// (max, sum, o[64]) -- no workgroup barrier inside the row loop -- and the NS partial results are merged ONCE, in
+// stream order.  fp32 softmax, bf16 head output.
+// Which workgroup runs which stream is a launch-shape choice that cannot change a single bit of the result: nsplit
+// (1, 2, 4 or 8) workgroups of NS / nsplit waves share a pair when there are too few pairs to fill the chip (they
+// leave (m, l, o[64]) per stream in `part` and dec_attn_combine_kernel performs the same merge), one workgroup of NS
+// waves takes the whole pair otherwise and writes the head output itself.  Tokens therefore do not depend on the size
+// of the decode group (bit-level batch invariance; the round-1 kernels switched arithmetic with the batch).
+// NT: non-temporal loads (a cross-attention cache row is read once per step).
 constexpr int ATT_MAXK = 1536;
 
-// NIT = ceil(max keys per workgroup / 128): 12 covers the 1500 encoder frames, 4 the 448-token
-// self-attention cache.  Every K row a lane needs is requested in ONE batch, the V rows are
-// requested as soon as the scores are out of the K registers (they do not depend on the softmax),
-// so the kernel has two overlapped memory rounds instead of 2*NIT/4 serialised ones; scores and
-// probabilities stay in registers (no LDS pass over them), two workgroup barriers in total.
-template <int NIT>
-__global__ __launch_bounds__(1024) void dec_attn_kernel(const float *__restrict__ q,
-                                                        const bf16_t *__restrict__ kc,
-                                                        const bf16_t *__restrict__ vc, int H, int d,
-                                                        int T_stride, int n_keys_const,
-                                                        const int *__restrict__ pos_ptr, int nsplit,
-                                                        float *__restrict__ part, bf16_t *__restrict__ att,
-                                                        int n_bh, int n_wg, const char *pf_ptr,
-                                                        long pf_tile_bytes) {
-    if ((int)blockIdx.x >= n_wg) {  // L2 warm-up workgroup for the next GEMV's weights (see l2_warm_tile)
-        l2_warm_tile(pf_ptr, pf_tile_bytes, (int)blockIdx.x - n_wg, 1024);
-        return;
+// merged head-output element e of a pair from its NS stream partials (m, l, o): the one place the merge is written
+template <int NS>
+__device__ __forceinline__ float attn_merge(const float *m, const float *l, const float *o, int ostride, int e) {
+    float M = m[0];
+#pragma unroll
+    for (int w = 1; w < NS; ++w) M = fmaxf(M, m[w]);
+    float acc = 0.f, L = 0.f;
+#pragma unroll
+    for (int w = 0; w < NS; ++w) {
+        const float f = __expf(m[w] - M);  // a stream that saw no row has m = -1e30, l = 0, o = 0
+        acc = __fmaf_rn(o[w * ostride + e], f, acc);
+        L = __fmaf_rn(l[w], f, L);
     }
-    __shared__ float wred[ATT_NW];
-    __shared__ float wl[ATT_NW];
-    __shared__ float wacc[ATT_NW][64];
-    // n_wg <= n_bh compute workgroups walk the (sequence, head) pairs: a workgroup of this kernel owns its CU's whole
-    // register file, so capping the grid is what leaves CUs to the kernels of the other decode groups in flight.
-    for (int bh = blockIdx.x; bh < n_bh; bh += n_wg) {
-    if (bh != (int)blockIdx.x) __syncthreads();  // the previous pair's LDS reductions have been read
-    const int b = bh / H, h = bh % H, sp = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rg = lane >> 3, e8 = lane & 7;
-    const int n_keys = pos_ptr ? (*pos_ptr + 1) : n_keys_const;
-    int chunk = (n_keys + nsplit - 1) / nsplit;
-    chunk = (chunk + 7) & ~7;
-    const int start = sp * chunk;
-    int end = start + chunk;
-    if (end > n_keys) end = n_keys;
-    const int cnt = end > start ? end - start : 0;
-    const int last = cnt > 0 ? cnt - 1 : 0;
-    const bf16_t *kb = kc + ((long)bh * T_stride + start) * 64 + e8 * 8;
-    const bf16_t *vb = vc + ((long)bh * T_stride + start) * 64 + e8 * 8;
-
-    // ---- K rows: one batch of loads -------------------------------------------------------
-    u32x4 kv[NIT];
-#pragma unroll
-    for (int u = 0; u < NIT; ++u) {
-        int i = u * (ATT_NW * 8) + wave * 8 + rg;
-        i = i < cnt ? i : last;  // clamped: unconditional load
-        kv[u] = __builtin_nontemporal_load((const u32x4 *)(kb + (long)i * 64));
-    }
-    float qe[8];
-    {
-        const float *qp = q + (long)b * d + h * 64 + e8 * 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) qe[i] = qp[i] * 0.125f;  // hd^-0.5 (== hd^-0.25 on q and on k)
-    }
-    float sc[NIT];
-    float mloc = -1e30f;
-#pragma unroll
-    for (int u = 0; u < NIT; ++u) {
-        const int i = u * (ATT_NW * 8) + wave * 8 + rg;
-        float a = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            a += qe[2 * j] * __uint_as_float(kv[u][j] << 16);
-            a += qe[2 * j + 1] * __uint_as_float(kv[u][j] & 0xffff0000u);
-        }
-        a += __shfl_xor(a, 1);
-        a += __shfl_xor(a, 2);
-        a += __shfl_xor(a, 4);
-        sc[u] = i < cnt ? a : -1e30f;
-        mloc = fmaxf(mloc, sc[u]);
-    }
-    // ---- V rows requested now: in flight during the max reduction and the exponentials -------
-    u32x4 vv[NIT];
-#pragma unroll
-    for (int u = 0; u < NIT; ++u) {
-        int i = u * (ATT_NW * 8) + wave * 8 + rg;
-        i = i < cnt ? i : last;
-        vv[u] = __builtin_nontemporal_load((const u32x4 *)(vb + (long)i * 64));
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mloc = fmaxf(mloc, __shfl_xor(mloc, o));
-    if (lane == 0) wred[wave] = mloc;
-    __syncthreads();
-    float M = wred[0];
-#pragma unroll
-    for (int w = 1; w < ATT_NW; ++w) M = fmaxf(M, wred[w]);
-    // ---- p = exp(s - M), o = sum_i p_i V[i] ---------------------------------------------------
-    float oa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float lloc = 0.f;
-#pragma unroll
-    for (int u = 0; u < NIT; ++u) {
-        const float pv = sc[u] > -1e29f ? __expf(sc[u] - M) : 0.f;
-        lloc += pv;  // every one of the 8 lanes of a row holds the same pv: counted once below
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            oa[2 * j] += pv * __uint_as_float(vv[u][j] << 16);
-            oa[2 * j + 1] += pv * __uint_as_float(vv[u][j] & 0xffff0000u);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        oa[i] += __shfl_xor(oa[i], 8);
-        oa[i] += __shfl_xor(oa[i], 16);
-        oa[i] += __shfl_xor(oa[i], 32);
-    }
-    lloc += __shfl_xor(lloc, 8);
-    lloc += __shfl_xor(lloc, 16);
-    lloc += __shfl_xor(lloc, 32);
-    if (rg == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) wacc[wave][e8 * 8 + i] = oa[i];
-        if (e8 == 0) wl[wave] = lloc;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        float o = 0.f, L = 0.f;
-#pragma unroll
-        for (int w = 0; w < ATT_NW; ++w) {
-            o += wacc[w][tid];
-            L += wl[w];
-        }
-        if (nsplit == 1) {
-            att[(long)b * d + h * 64 + tid] = f2bf(o / L);
-        } else {
-            float *po = part + ((long)bh * nsplit + sp) * 66;
-            po[2 + tid] = o;
-            if (tid == 0) {
-                po[0] = cnt > 0 ? M : -1e30f;
-                po[1] = cnt > 0 ? L : 0.f;
-            }
-        }
-    }
-    }  // (sequence, head) pairs of this workgroup
+    return acc / L;
 }
 
-// ------------------------------------------------------------------ causal self-attention (decode)
-// The self-attention cache holds <= 448 rows and ~115 on average over a 224-token decode: a (sequence, head) pair
-// is 15-57 KB, far too little for the 16-wave streaming kernel above (its workgroups fill the chip 2 per CU, and at
-// 32 sequences x 20 heads they need two rounds).  Here a pair is ONE 4-wave workgroup (8 resident per CU): the waves
-// walk the rows in blocks of 128 (4 waves x 8 rows x 4 loads; K and V of a block requested together), each wave
-// keeps its own running (max, sum, o[64]) -- no workgroup barrier inside the loop -- and the four partial results
-// are merged once through LDS.  fp32 softmax, bf16 head output, same row -> lane mapping as dec_attn_kernel.
-// The same kernel with 8 waves x 6 loads (blocks of 384 rows) is the cross-attention when several decode groups are
-// in flight: ~90 VGPRs let two workgroups share a CU, so one streams while the other reduces; n_wg <= n_bh workgroups
-// walk the pairs.  NT: non-temporal loads (a cache row is read once per step).
-template <int NW, int U, bool NT>
-__global__ __launch_bounds__(NW * 64) void dec_rows_attn_kernel(const float *__restrict__ q,
+template <int NS, int U, bool NT>
+__global__ __launch_bounds__(NS * 64) void dec_rows_attn_kernel(const float *__restrict__ q,
                                                                 const bf16_t *__restrict__ kc,
                                                                 const bf16_t *__restrict__ vc, int H, int d,
                                                                 int T_stride, int n_keys_const,
                                                                 const int *__restrict__ pos_ptr,
-                                                                bf16_t *__restrict__ att, int n_bh, int n_wg,
+                                                                bf16_t *__restrict__ att, float *__restrict__ part,
+                                                                int nsplit, int n_bh, int n_wg,
                                                                 const char *pf_ptr, long pf_tile_bytes) {
     if ((int)blockIdx.x >= n_wg) {  // L2 warm-up workgroup for the next GEMV's weights
-        l2_warm_tile(pf_ptr, pf_tile_bytes, (int)blockIdx.x - n_wg, NW * 64);
+        l2_warm_tile(pf_ptr, pf_tile_bytes, (int)blockIdx.x - n_wg, blockDim.x);
         return;
     }
-    __shared__ float wm_[NW], wl_[NW];
-    __shared__ float wo_[NW][64];
+    __shared__ float wm_[NS], wl_[NS];
+    __shared__ float wo_[NS][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rg = lane >> 3, e8 = lane & 7;
     const int n_keys = pos_ptr ? (*pos_ptr + 1) : n_keys_const;
     const int last = n_keys - 1;
+    const int stream = (int)blockIdx.y * (NS / nsplit) + wave;  // blockDim.x == (NS / nsplit) * 64
+    // n_wg <= n_bh workgroups (per split) walk the (sequence, head) pairs
     for (int bh = blockIdx.x; bh < n_bh; bh += n_wg) {
         if (bh != (int)blockIdx.x) __syncthreads();  // the previous pair's merge has been read
         const int b = bh / H, h = bh % H;
@@ -587,15 +530,15 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_attn_kernel(const float *__r
         {
             const float *qp = q + (long)b * d + h * 64 + e8 * 8;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) qe[i] = qp[i] * 0.125f;  // hd^-0.5
+            for (int i = 0; i < 8; ++i) qe[i] = qp[i] * 0.125f;  // hd^-0.5 (== hd^-0.25 on q and on k)
         }
         float m_run = -1e30f, l_run = 0.f;
         float oa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int r0 = 0; r0 < n_keys; r0 += NW * 8 * U) {  // workgroup-uniform trip count
+        for (int r0 = 0; r0 < n_keys; r0 += NS * 8 * U) {  // workgroup-uniform trip count
             u32x4 kv[U], vv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                int i = r0 + u * (NW * 8) + wave * 8 + rg;
+                int i = r0 + u * (NS * 8) + stream * 8 + rg;
                 i = i < n_keys ? i : last;  // clamped: unconditional loads
                 if (NT) {
                     kv[u] = __builtin_nontemporal_load((const u32x4 *)(kb + (long)i * 64));
@@ -609,12 +552,12 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_attn_kernel(const float *__r
             float mb = -1e30f;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int i = r0 + u * (NW * 8) + wave * 8 + rg;
+                const int i = r0 + u * (NS * 8) + stream * 8 + rg;
                 float a = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    a += qe[2 * j] * __uint_as_float(kv[u][j] << 16);
-                    a += qe[2 * j + 1] * __uint_as_float(kv[u][j] & 0xffff0000u);
+                    a = __fmaf_rn(qe[2 * j], __uint_as_float(kv[u][j] << 16), a);
+                    a = __fmaf_rn(qe[2 * j + 1], __uint_as_float(kv[u][j] & 0xffff0000u), a);
                 }
                 a += __shfl_xor(a, 1);
                 a += __shfl_xor(a, 2);
@@ -636,8 +579,8 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_attn_kernel(const float *__r
                 l_run += pv;  // the 8 lanes of a row hold the same pv: only the row groups are summed below
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    oa[2 * j] += pv * __uint_as_float(vv[u][j] << 16);
-                    oa[2 * j + 1] += pv * __uint_as_float(vv[u][j] & 0xffff0000u);
+                    oa[2 * j] = __fmaf_rn(pv, __uint_as_float(vv[u][j] << 16), oa[2 * j]);
+                    oa[2 * j + 1] = __fmaf_rn(pv, __uint_as_float(vv[u][j] & 0xffff0000u), oa[2 * j + 1]);
                 }
             }
             m_run = m_new;
@@ -651,6 +594,18 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_attn_kernel(const float *__r
         l_run += __shfl_xor(l_run, 8);
         l_run += __shfl_xor(l_run, 16);
         l_run += __shfl_xor(l_run, 32);
+        if (nsplit > 1) {  // workgroup-uniform: the stream partials go to HBM, dec_attn_combine_kernel merges them
+            if (rg == 0) {
+                float *po = part + ((long)bh * NS + stream) * 66;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) po[2 + e8 * 8 + i] = oa[i];
+                if (e8 == 0) {
+                    po[0] = m_run;
+                    po[1] = l_run;
+                }
+            }
+            continue;
+        }
         if (rg == 0) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) wo_[wave][e8 * 8 + i] = oa[i];
@@ -660,36 +615,24 @@ __global__ __launch_bounds__(NW * 64) void dec_rows_attn_kernel(const float *__r
             }
         }
         __syncthreads();
-        if (tid < 64) {
-            float M = wm_[0];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) M = fmaxf(M, wm_[w]);
-            float o = 0.f, L = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const float f = __expf(wm_[w] - M);  // a wave that saw no row has m = -1e30, l = 0, o = 0
-                o += wo_[w][tid] * f;
-                L += wl_[w] * f;
-            }
-            att[(long)b * d + h * 64 + tid] = f2bf(o / L);
-        }
+        if (tid < 64) att[(long)b * d + h * 64 + tid] = f2bf(attn_merge<NS>(wm_, wl_, &wo_[0][0], 64, tid));
     }
 }
 
-// Combine flash-decoding partials -> bf16 head outputs.  grid B*H, 64 threads.
-__global__ __launch_bounds__(64) void dec_attn_combine_kernel(const float *__restrict__ part, int nsplit, int H,
-                                                              int d, bf16_t *__restrict__ att) {
+// Merge the NS stream partials of every pair -> bf16 head outputs (same arithmetic as the in-kernel merge).
+// grid B*H, 64 threads.
+template <int NS>
+__global__ __launch_bounds__(64) void dec_attn_combine_kernel(const float *__restrict__ part, int H, int d,
+                                                              bf16_t *__restrict__ att) {
+    __shared__ float wm_[NS], wl_[NS];
     const int bh = blockIdx.x, b = bh / H, h = bh % H, e = threadIdx.x;
-    const float *pp = part + (long)bh * nsplit * 66;
-    float M = -1e30f;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, pp[s * 66]);
-    float den = 0.f, num = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float w = __expf(pp[s * 66] - M);
-        den += w * pp[s * 66 + 1];
-        num += w * pp[s * 66 + 2 + e];
+    const float *pp = part + (long)bh * NS * 66;
+    if (e < NS) {
+        wm_[e] = pp[e * 66];
+        wl_[e] = pp[e * 66 + 1];
     }
-    att[(long)b * d + h * 64 + e] = f2bf(num / den);
+    __syncthreads();
+    att[(long)b * d + h * 64 + e] = f2bf(attn_merge<NS>(wm_, wl_, pp + 2, 66, e));
 }
 
 // ------------------------------------------------------------------ arg-max -> next token
@@ -706,11 +649,13 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
                                                              const bf16_t *__restrict__ emb,
                                                              const float *__restrict__ pemb, int d, int n_ctx,
                                                              float *__restrict__ x, bf16_t *__restrict__ xb,
-                                                             float *__restrict__ stats_out, WmTsDev ts) {
-    __shared__ int tok_s[WM_DEC_MAXB];
+                                                             float *__restrict__ stats_out, WmTsDev ts,
+                                                             int *__restrict__ arrive, int fallback_tok) {
+    __shared__ int tok_s[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pos = pos_ptr ? *pos_ptr : 0;
-    for (int b = wave; b < B; b += 16) {  // wave-uniform: one row per wave up to B = 16, two up to 32
+    const int bw = blockIdx.x * 16;  // this workgroup's rows: one per wave
+    for (int b = bw + wave; b < B && b < bw + 16; b += 16) {  // wave-uniform, at most one trip
         const unsigned long long *row = tilemax + (long)b * n_tiles;
         unsigned long long key = 0ull;
         for (int t0 = lane; t0 < n_tiles; t0 += 64 * 8) {
@@ -761,7 +706,8 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
             else key = kts > key ? kts : key;                                  // arg-max over everything allowed
         }
         if (lane == 0) {
-            const int tok = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+            // key == 0: nothing admissible (every allowed id suppressed, or NaN logits): never index with -1
+            const int tok = key ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : fallback_tok;
             if (ts.rng && pos + 1 >= n_prompt) {
                 // the token at index pos + 1 was sampled: advance the history and derive the ranges of the next position
                 int *hs = ts.hist + b * 4;
@@ -786,14 +732,14 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
                 if (pos + 1 >= n_prompt) seq[(pos + 1) * B + b] = tok;
                 else nxt = seq[(pos + 1) * B + b];
             }
-            tok_s[b] = nxt;
+            tok_s[b - bw] = nxt;
             if (result) result[b] = tok - arg_first;
         }
     }
     __syncthreads();
     if (x && pos + 1 < n_ctx) {
-        for (int b = wave; b < B; b += 16) {
-            const long tok = tok_s[b];
+        for (int b = bw + wave; b < B && b < bw + 16; b += 16) {
+            const long tok = tok_s[b - bw];
             float s1 = 0.f, s2 = 0.f;
             for (int j = lane; j < d; j += 64) {
                 const float v = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)(pos + 1) * d + j];
@@ -814,7 +760,16 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
             }
         }
     }
-    if (threadIdx.x == 0 && pos_ptr) *pos_ptr = pos + 1;
+    // *pos_ptr has ONE writer: the last workgroup to arrive (every workgroup read the position before it arrived)
+    __syncthreads();
+    if (threadIdx.x == 0 && pos_ptr) {
+        if (gridDim.x == 1) {
+            *pos_ptr = pos + 1;
+        } else if (atomicAdd(arrive, 1) == (int)gridDim.x - 1) {
+            *arrive = 0;
+            *pos_ptr = pos + 1;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ synthetic weights ----
@@ -858,23 +813,33 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(void *dst, int is_bf16,
     }
 }
 
-template <int EPI, bool LN>
-int launch_gemv(wm_ctx *ctx, const DecGemvDev &p, int spw, int nw, int grid) {
+template <int SPW, int EPI, bool LN>
+int launch_gemv_shape(wm_ctx *ctx, const DecGemvDev &p, int tn, int nblk, int nw, int grid) {
     hipStream_t s = ctx->stream;
-    const size_t lds = (size_t)2 * nw * 1024 + 16 * 2 * 4;
+    const size_t lds = (size_t)nw * tn * nblk * 1024 + (size_t)nw * 32 * 4;
     const int th = nw * 64;
-    switch (spw) {
-        case 2: dec_gemv_kernel<2, EPI, LN><<<grid, th, lds, s>>>(p); break;
-        case 4: dec_gemv_kernel<4, EPI, LN><<<grid, th, lds, s>>>(p); break;
-        case 5: dec_gemv_kernel<5, EPI, LN><<<grid, th, lds, s>>>(p); break;
-        case 6: dec_gemv_kernel<6, EPI, LN><<<grid, th, lds, s>>>(p); break;
-        case 8: dec_gemv_kernel<8, EPI, LN><<<grid, th, lds, s>>>(p); break;
-        case 10: dec_gemv_kernel<10, EPI, LN><<<grid, th, lds, s>>>(p); break;
-        case 12: dec_gemv_kernel<12, EPI, LN><<<grid, th, lds, s>>>(p); break;
-        default: wm_set_error("dec_gemv: unsupported k-steps per wave %d", spw); return WM_ERR_INVALID;
-    }
+    constexpr bool WIDE = LN && (EPI == DE_QKV || EPI == DE_GELU || EPI == DE_LOGITS) && SPW <= 6;
+    if (tn == 1 && nblk == 1) dec_gemv_kernel<SPW, 1, 1, EPI, LN><<<grid, th, lds, s>>>(p);
+    else if (tn == 1 && nblk == 2 && SPW <= 8) dec_gemv_kernel<SPW <= 8 ? SPW : 2, 1, 2, EPI, LN><<<grid, th, lds, s>>>(p);
+    else if (tn == 2 && nblk == 2 && WIDE) dec_gemv_kernel<WIDE ? SPW : 2, 2, 2, EPI, LN><<<grid, th, lds, s>>>(p);
+    else if (tn == 4 && nblk == 2 && WIDE) dec_gemv_kernel<WIDE ? SPW : 2, 4, 2, EPI, LN><<<grid, th, lds, s>>>(p);
+    else { wm_set_error("dec_gemv: unsupported launch shape (tn %d, nblk %d, spw %d)", tn, nblk, SPW); return WM_ERR_INVALID; }
     WM_HIP(hipGetLastError());
     return WM_OK;
+}
+
+template <int EPI, bool LN>
+int launch_gemv(wm_ctx *ctx, const DecGemvDev &p, int spw, int tn, int nblk, int nw, int grid) {
+    switch (spw) {
+        case 2: return launch_gemv_shape<2, EPI, LN>(ctx, p, tn, nblk, nw, grid);
+        case 4: return launch_gemv_shape<4, EPI, LN>(ctx, p, tn, nblk, nw, grid);
+        case 5: return launch_gemv_shape<5, EPI, LN>(ctx, p, tn, nblk, nw, grid);
+        case 6: return launch_gemv_shape<6, EPI, LN>(ctx, p, tn, nblk, nw, grid);
+        case 8: return launch_gemv_shape<8, EPI, LN>(ctx, p, tn, nblk, nw, grid);
+        case 10: return launch_gemv_shape<10, EPI, LN>(ctx, p, tn, nblk, nw, grid);
+        case 12: return launch_gemv_shape<12, EPI, LN>(ctx, p, tn, nblk, nw, grid);
+        default: wm_set_error("dec_gemv: unsupported k-steps per wave %d", spw); return WM_ERR_INVALID;
+    }
 }
 
 }  // namespace
@@ -895,12 +860,26 @@ int wm_dec_gemv_split(int K, int *spw) {
     return 0;
 }
 
-// Workgroups per weight tile at batch B (a scheduling choice: every row's arithmetic is the same for any value).
-static int pick_bgroups(int B) {
-    static const int env = getenv("WM_GEMV_BG") ? atoi(getenv("WM_GEMV_BG")) : 0;
-    const int nblk = (B + 15) / 16;
-    const int want = env > 0 ? env : 4;
-    return nblk < want ? nblk : want;
+// Launch shape at batch B -- tiles per workgroup (TN), batch blocks per workgroup (NBLK) and workgroups per tile group
+// (bgroups).  A scheduling choice only: every output element is computed by the same instruction sequence for any shape.
+// Small batches (one block): one tile per workgroup, as many workgroups as tiles (latency).  Large batches: two blocks
+// per workgroup and, for the wide matrices, 2 or 4 tiles per workgroup so that the grid stays near one round of the chip
+// and an activation fragment is fetched once per TN products.
+static void pick_shape(int epi, bool ln, int spw, int B, int n_tiles, int *tn, int *nblk) {
+    static const int env_tn = getenv("WM_GEMV_TN") ? atoi(getenv("WM_GEMV_TN")) : 0;
+    static const int env_nb = getenv("WM_GEMV_NBLK") ? atoi(getenv("WM_GEMV_NBLK")) : 0;
+    const int blocks = (B + 15) / 16;
+    *tn = 1;
+    *nblk = 1;
+    if (blocks < 2 || spw > 8) return;  // one block, or the 16-wave K = 4d products (register budget): one unit
+    *nblk = env_nb == 1 ? 1 : 2;
+    const bool wide = ln && (epi == DE_QKV || epi == DE_GELU || epi == DE_LOGITS) && *nblk == 2 && spw <= 6;
+    if (!wide) return;
+    const int g = (blocks + 1) / 2;
+    int t = 1;
+    while (t < 4 && (n_tiles / (2 * t)) * g >= 256) t *= 2;  // keep >= 256 workgroups
+    if (env_tn == 1 || env_tn == 2 || env_tn == 4) t = env_tn;
+    *tn = t;
 }
 
 int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
@@ -924,12 +903,15 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     p.ldo = a.ldo; p.tilemax = a.argmax; p.arg_first = a.arg_first; p.arg_last = a.arg_last;
     p.mask = a.mask; p.mask_words = a.mask_words; p.mask_first_pos = a.mask_first_pos;
     p.ts = a.ts;
-    p.bgroups = pick_bgroups(a.B);
     p.n_tiles = (a.N + 15) / 16;
-    p.n_tiles_pad = p.bgroups > 1 ? (p.n_tiles + 7) / 8 * 8 : p.n_tiles;  // (tile, group) decode in the kernel needs rows of 8
-    int grid = p.n_tiles_pad * p.bgroups;
+    int tn = 1, nblk = 1;
+    pick_shape(a.epi, ln, spw, a.B, p.n_tiles, &tn, &nblk);
+    p.bgroups = ((a.B + 15) / 16 + nblk - 1) / nblk;
+    p.n_tg = (p.n_tiles + tn - 1) / tn;
+    p.n_tg_pad = p.bgroups > 1 ? (p.n_tg + 7) / 8 * 8 : p.n_tg;  // (tile group, batch group) decode needs rows of 8
+    int grid = p.n_tg_pad * p.bgroups;
     static const bool no_pf = getenv("WM_NO_PREFETCH") != nullptr;
-    if (!no_pf && a.pf_ptr && a.pf_rows >= 16 && p.n_tiles % 8 == 0) {
+    if (!no_pf && a.pf_ptr && a.pf_rows >= 16 && grid % 8 == 0) {
         p.pf_ptr = (const char *)a.pf_ptr;
         p.pf_tile_bytes = 16L * a.pf_k * 2;
         p.pf_tiles = a.pf_rows / 16;
@@ -938,27 +920,27 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     switch (a.epi * 2 + (ln ? 1 : 0)) {
         case DE_QKV * 2 + 1: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_qkv", ctx->stream);
-            return launch_gemv<DE_QKV, true>(ctx, p, spw, nw, grid);
+            return launch_gemv<DE_QKV, true>(ctx, p, spw, tn, nblk, nw, grid);
         }
         case DE_Q * 2 + 1: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_q", ctx->stream);
-            return launch_gemv<DE_Q, true>(ctx, p, spw, nw, grid);
+            return launch_gemv<DE_Q, true>(ctx, p, spw, tn, nblk, nw, grid);
         }
         case DE_GELU * 2 + 1: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_fc1", ctx->stream);
-            return launch_gemv<DE_GELU, true>(ctx, p, spw, nw, grid);
+            return launch_gemv<DE_GELU, true>(ctx, p, spw, tn, nblk, nw, grid);
         }
         case DE_LOGITS * 2 + 1: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_logits", ctx->stream);
-            return launch_gemv<DE_LOGITS, true>(ctx, p, spw, nw, grid);
+            return launch_gemv<DE_LOGITS, true>(ctx, p, spw, tn, nblk, nw, grid);
         }
         case DE_RESID * 2: {
             WmProfScope ps(&ctx->prof, a.K > a.N ? "dec_gemv_fc2" : "dec_gemv_attn_out", ctx->stream);
-            return launch_gemv<DE_RESID, false>(ctx, p, spw, nw, grid);
+            return launch_gemv<DE_RESID, false>(ctx, p, spw, tn, nblk, nw, grid);
         }
         case DE_Q * 2: {
             WmProfScope ps(&ctx->prof, "dec_gemv_plain", ctx->stream);
-            return launch_gemv<DE_Q, false>(ctx, p, spw, nw, grid);
+            return launch_gemv<DE_Q, false>(ctx, p, spw, tn, nblk, nw, grid);
         }
         default:
             wm_set_error("dec_gemv: unsupported (epilogue %d, LayerNorm %d) pair", a.epi, (int)ln);
@@ -982,53 +964,34 @@ int wm_dec_embed(wm_ctx *ctx, const int *seq, const int *pos_ptr, int B, const b
     return WM_OK;
 }
 
+// Workgroups per (sequence, head) pair of the cross-attention: 1 when the pairs alone fill the chip, else the stream
+// set of a pair is dealt to 2, 4 or 8 workgroups.  A launch-shape choice: the arithmetic does not depend on it.
 int wm_dec_attn_splits(int B, int H) {
     const int bh = B * H;
     if (bh >= 96) return 1;
-    int ns = (192 + bh - 1) / bh;
-    return ns > 8 ? 8 : ns;
+    int ns = 2;
+    while (ns < 8 && bh * ns < 192) ns *= 2;
+    return ns;
 }
 
 int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
                      int T_stride, int n_keys, const int *pos_ptr, int nsplit, float *part, bf16_t *att,
                      bool cross, const bf16_t *pf_ptr, int pf_rows, int pf_k) {
-    WM_REQUIRE(nsplit >= 1 && nsplit <= 8, WM_ERR_INVALID, "dec_attention: nsplit %d out of range", nsplit);
+    WM_REQUIRE(nsplit == 1 || nsplit == 2 || nsplit == 4 || nsplit == 8, WM_ERR_INVALID,
+               "dec_attention: nsplit %d is not 1, 2, 4 or 8", nsplit);
     WM_REQUIRE(T_stride <= ATT_MAXK && n_keys <= ATT_MAXK, WM_ERR_INVALID,
                "dec_attention: more than %d keys", ATT_MAXK);
+    WM_REQUIRE(nsplit == 1 || part != nullptr, WM_ERR_INVALID, "dec_attention: split launch without a partials buffer");
     {
         WmProfScope ps(&ctx->prof, cross ? "dec_attn_cross" : "dec_attn_self", ctx->stream);
         static const bool no_pf = getenv("WM_NO_PREFETCH") != nullptr;
-        // Cross-attention over the full cache (nsplit == 1): the block-streaming kernel with 8 waves x 4 loads --
-        // ~90 VGPRs, so two workgroups (or a GEMV of another decode group) share a CU -- and at most 256 workgroups
-        // walking the pairs.  Measured alone at B = 8 / 32 / 64: 12.5-13.8 / 41 / 75 us (4.6-4.9 / 6.0 / 6.5 TB/s) against
-        // 14.2 / 47 / 92 us for the 16-wave kernel below; under three-way concurrency both saturate at 6.7-7.0 TB/s.
-        // WM_XATTN_ROWS=0 selects the 16-wave kernel, WM_XATTN_WGS the workgroup cap (A/B probes).
-        static const int rows_mode = getenv("WM_XATTN_ROWS") ? atoi(getenv("WM_XATTN_ROWS")) : 1;
-        if (cross && nsplit == 1 && rows_mode > 0 && !pos_ptr) {
-            static const int env_cap2 = getenv("WM_XATTN_WGS") ? atoi(getenv("WM_XATTN_WGS")) : 0;
-            const int cap2 = env_cap2 > 0 ? env_cap2 : 256;
-            int n_wg = B * H;
-            if (n_wg > cap2) {
-                const int rounds = (n_wg + cap2 - 1) / cap2;
-                n_wg = (n_wg + rounds - 1) / rounds;  // balanced: every workgroup walks `rounds` (or rounds - 1) pairs
-            }
-            int gx = n_wg;
-            long tile_bytes = 0;
-            if (!no_pf && pf_ptr && gx % 8 == 0 && pf_rows >= 16) {
-                tile_bytes = 16L * pf_k * 2;
-                gx += pf_rows / 16;
-            }
-            dec_rows_attn_kernel<8, 4, true><<<gx, 512, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, nullptr, att,
-                                                                         B * H, n_wg, (const char *)pf_ptr, tile_bytes);
-            WM_HIP(hipGetLastError());
-            return WM_OK;
-        }
-        // Compute workgroups: one per (sequence, head) up to a cap (default 160 = what B = 8 x 20 heads uses; measured:
-        // more than that blocks the CUs the other decode groups need).  WM_XATTN_WGS overrides (A/B probes).
+        // 8 streams x 4 loads: ~90-120 VGPRs, so two workgroups (or a GEMV of another decode group) share a CU; at most
+        // 256 workgroups walk the pairs.  Measured alone at B = 8 / 32 / 64: 12.5-13.8 / 41 / 75 us (4.6-4.9 / 6.0 /
+        // 6.5 TB/s); under three-way concurrency the stream saturates at 6.7-7.0 TB/s.  WM_XATTN_WGS: workgroup cap (A/B).
         static const int env_cap = getenv("WM_XATTN_WGS") ? atoi(getenv("WM_XATTN_WGS")) : 0;
-        const int cap = env_cap > 0 ? env_cap : 160;
+        const int cap = env_cap > 0 ? env_cap : 256;
         int n_wg = B * H;
-        if (cross && nsplit == 1 && n_wg > cap) {
+        if (n_wg > cap) {
             const int rounds = (n_wg + cap - 1) / cap;
             n_wg = (n_wg + rounds - 1) / rounds;  // balanced: every workgroup walks `rounds` (or rounds - 1) pairs
         }
@@ -1039,19 +1002,13 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
             gx += pf_rows / 16;
         }
         dim3 grid(gx, nsplit);
-        const int max_keys = pos_ptr ? T_stride : n_keys;
-        const int per_wg = ((max_keys + nsplit - 1) / nsplit + 7) & ~7;
-        if (per_wg <= 4 * ATT_NW * 8)
-            dec_attn_kernel<4><<<grid, 1024, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, nsplit,
-                                                              part, att, B * H, n_wg, (const char *)pf_ptr, tile_bytes);
-        else
-            dec_attn_kernel<12><<<grid, 1024, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, nsplit,
-                                                               part, att, B * H, n_wg, (const char *)pf_ptr, tile_bytes);
+        dec_rows_attn_kernel<8, 4, true><<<grid, (8 / nsplit) * 64, 0, ctx->stream>>>(
+            q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, nsplit, B * H, n_wg, (const char *)pf_ptr, tile_bytes);
         WM_HIP(hipGetLastError());
     }
     if (nsplit > 1) {
         WmProfScope ps(&ctx->prof, "dec_attn_combine", ctx->stream);
-        dec_attn_combine_kernel<<<B * H, 64, 0, ctx->stream>>>(part, nsplit, H, H * 64, att);
+        dec_attn_combine_kernel<8><<<B * H, 64, 0, ctx->stream>>>(part, H, H * 64, att);
         WM_HIP(hipGetLastError());
     }
     return WM_OK;
@@ -1069,21 +1026,25 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
         tile_bytes = 16L * pf_k * 2;
         gx += pf_rows / 16;
     }
+    // a pair is 15-57 KB of cache (<= 448 rows, ~115 on average over a 224-token decode): ONE 4-wave workgroup
     dec_rows_attn_kernel<4, 4, false><<<gx, 256, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att,
-                                                                  B * H, B * H, (const char *)pf_ptr, tile_bytes);
+                                                                  nullptr, 1, B * H, B * H, (const char *)pf_ptr, tile_bytes);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }
 
 int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
                     int n_prompt, int *result, int arg_first, const bf16_t *emb, const float *pemb, int d, int n_ctx,
-                    float *x, bf16_t *xb, float *stats_out, const WmTsDev *ts) {
+                    float *x, bf16_t *xb, float *stats_out, const WmTsDev *ts, int *arrive, int fallback_tok) {
     WmProfScope ps(&ctx->prof, "argmax_embed", ctx->stream);
     WmTsDev t;
     memset(&t, 0, sizeof(t));
     if (ts) t = *ts;
-    argmax_embed_kernel<<<1, 1024, 0, ctx->stream>>>(tilemax, n_tiles, B, seq, pos_ptr, n_prompt, result, arg_first,
-                                                     emb, pemb, d, n_ctx, x, xb, stats_out, t);
+    const int grid = arrive ? (B + 15) / 16 : 1;
+    WM_REQUIRE(grid == 1 || B <= 16 * grid, WM_ERR_INVALID, "argmax_embed: bad grid");
+    WM_REQUIRE(arrive || B <= 16, WM_ERR_INVALID, "argmax_embed: more than 16 rows need the arrival counter");
+    argmax_embed_kernel<<<grid, 1024, 0, ctx->stream>>>(tilemax, n_tiles, B, seq, pos_ptr, n_prompt, result, arg_first,
+                                                        emb, pemb, d, n_ctx, x, xb, stats_out, t, arrive, fallback_tok);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

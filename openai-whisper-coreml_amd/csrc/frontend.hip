@@ -110,6 +110,11 @@ __global__ __launch_bounds__(WPB * 64) void logmel_stage1(
     __shared__ T smem[SPAN_LDS > PW_LDS ? SPAN_LDS : PW_LDS];
     T *xs = smem;
     T(*pw)[16][PW_STRIDE] = (T(*)[16][PW_STRIDE])smem;
+    // non-finite power bins per frame.  The reference's mel product is DENSE (lib.rs:60-69 multiplies every bin by its
+    // weight, zero or not), so a non-finite bin that meets a zero weight turns the row into NaN (0 x Inf), which
+    // lib.rs:76 then floors to 1e-10; the banded sum below reproduces that from this count.
+    __shared__ int bad[WPB][16];
+    if (threadIdx.x < WPB * 16) bad[threadIdx.x >> 4][threadIdx.x & 15] = 0;
 
     const int chunk = blockIdx.x / blocks_per_chunk;
     const int f0 = (blockIdx.x % blocks_per_chunk) * FPB;
@@ -167,14 +172,20 @@ __global__ __launch_bounds__(WPB * 64) void logmel_stage1(
         for (int r = 0; r < 4; ++r) {
             const T ce = acc[0][j][r], co = acc[1][j][r], se = acc[2][j][r], so = acc[3][j][r];
             const int row = acc_row(T(0), lane, r);
+            int nbad = 0;
             if (k <= 100) {
                 const T re = ce + co, im = se + so;
-                pw[wave][row][k] = re * re + im * im;
+                const T pv = re * re + im * im;
+                pw[wave][row][k] = pv;
+                nbad += !(pv - pv == (T)0);  // Inf - Inf and NaN - NaN are NaN
             }
             if (k < 100) {
                 const T re = ce - co, im = so - se;
-                pw[wave][row][200 - k] = re * re + im * im;
+                const T pv = re * re + im * im;
+                pw[wave][row][200 - k] = pv;
+                nbad += !(pv - pv == (T)0);
             }
+            if (nbad) atomicAdd(&bad[wave][row], nbad);
         }
     }
     __syncthreads();
@@ -187,7 +198,14 @@ __global__ __launch_bounds__(WPB * 64) void logmel_stage1(
         const int ks = band_start[m], kl = band_len[m];
         const float *wrow = band_w + m * WM_MEL_MAXW;
         T s = 0;
-        for (int t = 0; t < kl; ++t) s += pw[wave][lane & 15][ks + t] * (T)wrow[t];
+        int inband = 0;
+        for (int t = 0; t < kl; ++t) {
+            const T pv = pw[wave][lane & 15][ks + t];
+            s += pv * (T)wrow[t];
+            inband += !(pv - pv == (T)0);
+        }
+        // a non-finite bin outside this row's band would have met a zero weight in the reference's dense sum: NaN
+        if (bad[wave][lane & 15] > inband) s = (T)0;
         s = (s > (T)1e-10) ? s : (T)1e-10;  // f64::max(1e-10): NaN -> 1e-10
         const T v = log10_t(s);
         if (live) {

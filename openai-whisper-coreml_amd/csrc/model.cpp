@@ -57,6 +57,7 @@ static int alloc_decode_buffers(WmModel *m, hipStream_t s) {
     WM_TRY(dalloc_t(m, &m->dresult, WM_DEC_MAXB, s));
     WM_TRY(dalloc_t(m, &m->dseq, (size_t)WM_DEC_MAXB * (D.n_text_ctx + 1), s));
     WM_TRY(dalloc_t(m, &m->dpos, 4, s));
+    WM_TRY(dalloc_t(m, &m->darrive, 4, s));
     WM_TRY(dalloc_t(m, &m->dts_rng, (size_t)WM_DEC_MAXB * 4, s));
     WM_TRY(dalloc_t(m, &m->dts_hist, (size_t)WM_DEC_MAXB * 4, s));
     WM_TRY(dalloc_t(m, &m->dts_key, (size_t)WM_DEC_MAXB * (m->vpad / 16), s));
@@ -82,6 +83,16 @@ int wm_model_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t ts_begin, int3
         const int V = m->dims.n_vocab;
         WM_REQUIRE(ts_begin > 0 && ts_begin < V && eot >= 0 && eot < ts_begin, WM_ERR_INVALID,
                    "timestamp rules: need 0 <= eot < timestamp_begin < n_vocab (%d)", V);
+        // <|endoftext|> is the token of last resort of the rules (an opening timestamp may be followed by it, and it is
+        // what the arg-max kernel falls back to when nothing else is admissible): it must not be suppressed
+        if (!m->mask_host.empty())
+            WM_REQUIRE(!((m->mask_host[eot >> 5] >> (eot & 31)) & 1u), WM_ERR_INVALID,
+                       "timestamp rules: <|endoftext|> (%d) is in the suppress list", eot);
+        if (m->ts_begin != ts_begin || m->ts_eot != eot || m->ts_max_initial != max_initial) {
+            // these ids are baked into the captured decode graph's kernel arguments: drop the stale capture
+            if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+            if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+        }
         m->ts_begin = ts_begin; m->ts_eot = eot; m->ts_max_initial = max_initial;
     }
     m->ts_on = enable != 0;
@@ -112,6 +123,10 @@ int wm_model_set_suppress(wm_ctx *ctx, const int32_t *ids, int n, const int32_t 
         live1 += !((bits[words + (t >> 5)] >> (t & 31)) & 1u);
     }
     WM_REQUIRE(live0 > 0 && live1 > 0, WM_ERR_INVALID, "set_suppress: every token would be suppressed");
+    if (m->ts_on)
+        WM_REQUIRE(!((bits[m->ts_eot >> 5] >> (m->ts_eot & 31)) & 1u), WM_ERR_INVALID,
+                   "set_suppress: <|endoftext|> (%d) must stay admissible while the timestamp rules are on", m->ts_eot);
+    m->mask_host.assign(bits.begin(), bits.begin() + words);   // the every-position list (timestamp-rule validation)
     WM_HIP(hipMemcpyAsync(m->dmask, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));
     m->mask_on = (n + n_first) > 0;
@@ -253,7 +268,7 @@ int wm_model_clone(wm_ctx *child, const wm_ctx *parent) {
     m->shares_weights = true;
     WM_TRY(alloc_decode_buffers(m, child->stream));
     WM_HIP(hipMemcpyAsync(m->dmask, pm->dmask, (size_t)2 * (m->vpad / 32) * 4, hipMemcpyDeviceToDevice, child->stream));
-    m->mask_on = pm->mask_on;
+    m->mask_on = pm->mask_on; m->mask_host = pm->mask_host;
     m->ts_on = pm->ts_on; m->ts_begin = pm->ts_begin; m->ts_eot = pm->ts_eot; m->ts_max_initial = pm->ts_max_initial;
     WM_HIP(hipStreamSynchronize(child->stream));
     return WM_OK;
@@ -605,5 +620,5 @@ int wm_model_close_step(wm_ctx *ctx, int B, int n_prompt, bool write_seq, int *r
     const WmTsDev t = wm_model_ts_dev(m);
     return wm_argmax_embed(ctx, m->dargmax, m->vpad / 16, B, write_seq ? m->dseq : nullptr, m->dpos, n_prompt, result,
                            arg_first, m->tok_emb, m->dec_pos, m->dims.n_text_state, m->dims.n_text_ctx, m->dx, m->dxb,
-                           m->dstats, use_ts ? &t : nullptr);
+                           m->dstats, use_ts ? &t : nullptr, m->darrive, use_ts ? m->ts_eot : arg_first);
 }

@@ -125,12 +125,14 @@ struct WmModel {
     int *dresult = nullptr;     // [16] arg-max result relative to arg_first
     int *dseq = nullptr;        // [n_text_ctx][16->B] token sequence (prompt, then generated), position-major
     int *dpos = nullptr;        // [1] current decode position (read by every decode kernel)
+    int *darrive = nullptr;     // [1] arrival counter of the arg-max workgroups (zero between launches)
     // captured decode step (one hipGraph replayed for every position)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_B = 0, graph_n_prompt = 0, graph_cap_b = 0, graph_mask = 0;
     unsigned *dmask = nullptr;   // [2][vpad/32] suppressed-token bitmaps (wm_set_suppress); [1] = first generated token
     bool mask_on = false;
+    std::vector<unsigned> mask_host;  // host copy of the every-position bitmap
     // timestamp rules (wm_set_timestamp_rules): per-sequence state and per-tile partials, see WmTsDev
     bool ts_on = false;
     int ts_begin = 0, ts_eot = 0, ts_max_initial = -1;
@@ -210,7 +212,7 @@ int wm_enc_attention(wm_ctx *ctx, const bf16_t *qk, const bf16_t *vt, bf16_t *at
 
 // dec_kernels.hip
 constexpr int WM_DEC_MAXB = 128;  // decode group: up to eight batch blocks of 16 rows (the MFMA M dimension)
-constexpr int WM_MAXSPLIT = 8;  // flash-decoding splits of single-query attention (small batches)
+constexpr int WM_MAXSPLIT = 8;  // stream partials of a (sequence, head) pair of the cross-attention (small batches)
 enum DecEpi { DE_QKV = 0, DE_Q = 1, DE_RESID = 2, DE_GELU = 3, DE_LOGITS = 4 };
 struct DecGemvArgs {
     int epi;
@@ -263,9 +265,12 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
 // chosen token of row b -> seq[(*pos_ptr + 1) * B + b] when that position is >= n_prompt;
 // (token - arg_first) -> result[b]; embed the tokens of position *pos_ptr + 1 into x (+ LayerNorm
 // partial statistics) when x != null; then *pos_ptr += 1.  seq / pos_ptr / result / x may be null.
+// arrive: zero-initialised device counter, required above 16 rows (one workgroup per 16 rows; the last one to arrive
+// advances the position).  fallback_tok: the token taken when nothing is admissible (all suppressed / NaN logits).
 int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
                     int n_prompt, int *result, int arg_first, const bf16_t *emb, const float *pemb, int d, int n_ctx,
-                    float *x, bf16_t *xb, float *stats_out, const WmTsDev *ts = nullptr);
+                    float *x, bf16_t *xb, float *stats_out, const WmTsDev *ts = nullptr, int *arrive = nullptr,
+                    int fallback_tok = 0);
 // initial timestamp-rule state of B sequences (before the first sampled token)
 int wm_ts_init(wm_ctx *ctx, const WmTsDev &ts, int B);
 int wm_range_softmax(wm_ctx *ctx, const float *logits, long ldo, int B, int first, int n, float *probs);

@@ -31,51 +31,51 @@ static int io_stage(wm_ctx *ctx, size_t bytes, char **out) {
     return WM_OK;
 }
 
-extern "C" int wm_set_tensor(wm_ctx *ctx, const char *name, const float *data, size_t n) {
+extern "C" int wm_set_tensor(wm_ctx *ctx, const char *name, const float *data, size_t n) try {
     WM_MODEL(ctx);
     (void)m;
     return wm_model_set_tensor(ctx, name, data, n);
-}
-extern "C" int wm_get_tensor(wm_ctx *ctx, const char *name, float *data, size_t n) {
+} WM_API_CATCH
+extern "C" int wm_get_tensor(wm_ctx *ctx, const char *name, float *data, size_t n) try {
     WM_MODEL(ctx);
     (void)m;
     return wm_model_get_tensor(ctx, name, data, n);
-}
-extern "C" int wm_init_synthetic(wm_ctx *ctx, uint64_t seed) {
+} WM_API_CATCH
+extern "C" int wm_init_synthetic(wm_ctx *ctx, uint64_t seed) try {
     WM_MODEL(ctx);
     (void)m;
     return wm_model_init_synthetic(ctx, seed);
-}
-extern "C" int wm_finalize(wm_ctx *ctx) {
+} WM_API_CATCH
+extern "C" int wm_finalize(wm_ctx *ctx) try {
     WM_MODEL(ctx);
     (void)m;
     return wm_model_finalize(ctx);
-}
-extern "C" int wm_set_suppress(wm_ctx *ctx, const int32_t *suppress, int n, const int32_t *suppress_first, int n_first) {
+} WM_API_CATCH
+extern "C" int wm_set_suppress(wm_ctx *ctx, const int32_t *suppress, int n, const int32_t *suppress_first, int n_first) try {
     WM_MODEL(ctx);
     (void)m;
     WM_TRY(wm_model_set_suppress(ctx, suppress, n, suppress_first, n_first));
     for (wm_ctx *lane : ctx->lanes) WM_TRY(wm_model_set_suppress(lane, suppress, n, suppress_first, n_first));
     return WM_OK;
-}
+} WM_API_CATCH
 extern "C" int wm_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t timestamp_begin, int32_t eot,
-                                      int32_t max_initial_timestamp_index) {
+                                      int32_t max_initial_timestamp_index) try {
     WM_MODEL(ctx);
     (void)m;
     WM_TRY(wm_model_set_timestamp_rules(ctx, enable, timestamp_begin, eot, max_initial_timestamp_index));
     for (wm_ctx *lane : ctx->lanes)
         WM_TRY(wm_model_set_timestamp_rules(lane, enable, timestamp_begin, eot, max_initial_timestamp_index));
     return WM_OK;
-}
-extern "C" int wm_get_dims(const wm_ctx *ctx, wm_dims *out) {
+} WM_API_CATCH
+extern "C" int wm_get_dims(const wm_ctx *ctx, wm_dims *out) try {
     WM_REQUIRE(ctx && out, WM_ERR_INVALID, "null pointer");
     WM_REQUIRE(ctx->model, WM_ERR_STATE, "context has no model");
     *out = ctx->model->dims;
     return WM_OK;
-}
+} WM_API_CATCH
 
 // Flat weight file (format: openai-whisper-coreml_amd/weights.py / DESIGN.md).
-extern "C" int wm_load_weights(wm_ctx *ctx, const char *path) {
+extern "C" int wm_load_weights(wm_ctx *ctx, const char *path) try {
     WM_MODEL(ctx);
     WM_REQUIRE(path, WM_ERR_INVALID, "null path");
     FILE *f = fopen(path, "rb");
@@ -94,6 +94,10 @@ extern "C" int wm_load_weights(wm_ctx *ctx, const char *path) {
         wm_set_error("'%s': model dimensions differ from the context's", path);
         st = WM_ERR_IO;
     }
+    if (st == WM_OK && count <= 0) {
+        wm_set_error("'%s': tensor count %d", path, count);
+        st = WM_ERR_IO;
+    }
     for (int i = 0; st == WM_OK && i < count; ++i) {
         int32_t nl = 0;
         int64_t ne = 0;
@@ -102,16 +106,25 @@ extern "C" int wm_load_weights(wm_ctx *ctx, const char *path) {
         if (fread(name.data(), 1, nl, f) != (size_t)nl || fread(&ne, 8, 1, f) != 1 || ne <= 0) {
             wm_set_error("'%s': truncated", path); st = WM_ERR_IO; break;
         }
+        // the element count comes from the file: check it against the registered tensor BEFORE allocating
+        auto it = m->index.find(name.data());
+        if (it == m->index.end()) { wm_set_error("'%s': unknown tensor '%s'", path, name.data()); st = WM_ERR_IO; break; }
+        if ((uint64_t)ne != (uint64_t)m->tensors[it->second].n_elems) {
+            wm_set_error("'%s': tensor '%s' has %lld elements, %zu expected", path, name.data(), (long long)ne,
+                         m->tensors[it->second].n_elems);
+            st = WM_ERR_IO;
+            break;
+        }
         buf.resize((size_t)ne);
         if (fread(buf.data(), 4, (size_t)ne, f) != (size_t)ne) { wm_set_error("'%s': truncated", path); st = WM_ERR_IO; break; }
         st = wm_model_set_tensor(ctx, name.data(), buf.data(), (size_t)ne);
     }
     fclose(f);
     return st;
-}
+} WM_API_CATCH
 
 // ------------------------------------------------------------------ encoder ------------
-extern "C" int wm_encode(wm_ctx *ctx, const float *mel, int B, float *xa, wm_mem mem) {
+extern "C" int wm_encode(wm_ctx *ctx, const float *mel, int B, float *xa, wm_mem mem) try {
     WM_MODEL(ctx);
     WM_REQUIRE(mel && xa && B >= 1, WM_ERR_INVALID, "null pointer / B < 1");
     if (mem == WM_MEM_DEVICE) return wm_model_encode_dev(ctx, mel, B, xa);
@@ -124,7 +137,7 @@ extern "C" int wm_encode(wm_ctx *ctx, const float *mel, int B, float *xa, wm_mem
     WM_HIP(hipMemcpyAsync(xa, st + in_b, out_b, hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));
     return WM_OK;
-}
+} WM_API_CATCH
 
 // ------------------------------------------------------------------ decoder ------------
 // Shared: bring xa (f32 [B][1500][d], host or device) into the bf16 encoder-output buffer
@@ -144,7 +157,7 @@ static int load_xa(wm_ctx *ctx, const float *xa, int B, wm_mem mem) {
 }
 
 extern "C" int wm_decode_logits(wm_ctx *ctx, const int32_t *tokens, int B, int T, const float *xa,
-                                float *logits, wm_mem mem) {
+                                float *logits, wm_mem mem) try {
     WM_MODEL(ctx);
     WM_REQUIRE(tokens && xa && logits, WM_ERR_INVALID, "null pointer");
     WM_REQUIRE(B >= 1 && B <= WM_DEC_MAXB, WM_ERR_INVALID, "B must be 1..%d", WM_DEC_MAXB);
@@ -204,21 +217,21 @@ extern "C" int wm_decode_logits(wm_ctx *ctx, const int32_t *tokens, int B, int T
     }
     if (st) (void)hipFree(st);
     return rc;
-}
+} WM_API_CATCH
 
 static int detect_language_impl(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first, int32_t lang_last,
                                 int32_t *lang_idx, float *probs, wm_mem mem);
 
 extern "C" int wm_detect_language(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first,
-                                  int32_t lang_last, int32_t *lang_idx, wm_mem mem) {
+                                  int32_t lang_last, int32_t *lang_idx, wm_mem mem) try {
     return detect_language_impl(ctx, xa, B, sot, lang_first, lang_last, lang_idx, nullptr, mem);
-}
+} WM_API_CATCH
 
 extern "C" int wm_detect_language_probs(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first,
-                                        int32_t lang_last, int32_t *lang_idx, float *probs, wm_mem mem) {
+                                        int32_t lang_last, int32_t *lang_idx, float *probs, wm_mem mem) try {
     WM_REQUIRE(probs != nullptr, WM_ERR_INVALID, "null pointer");
     return detect_language_impl(ctx, xa, B, sot, lang_first, lang_last, lang_idx, probs, mem);
-}
+} WM_API_CATCH
 
 static int detect_language_impl(wm_ctx *ctx, const float *xa, int B, int32_t sot, int32_t lang_first, int32_t lang_last,
                                 int32_t *lang_idx, float *probs, wm_mem mem) {
@@ -237,7 +250,7 @@ static int detect_language_impl(wm_ctx *ctx, const float *xa, int B, int32_t sot
     WM_TRY(wm_model_embed_first(ctx, B));
     WM_TRY(wm_model_decode_step(ctx, B, probs != nullptr, lang_first, lang_last));     // :36-37
     WM_TRY(wm_argmax_embed(ctx, m->dargmax, m->vpad / 16, B, nullptr, nullptr, 0, m->dresult, lang_first, nullptr,
-                           nullptr, 0, 0, nullptr, nullptr, nullptr));      // :38
+                           nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, m->darrive, lang_first));  // :38
     if (probs) {  // openai-whisper detect_language(): softmax over the language-token logits only
         const int n_lang = lang_last - lang_first + 1;
         float *d_probs = probs;
@@ -362,7 +375,7 @@ int lane_graph(LaneJob &j, int n_prompt) {
 
 extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int B,
                                     const int32_t *prompt, int n_prompt, int max_new, int32_t eot,
-                                    int32_t *tokens_out, int32_t *lens_out, wm_mem mem) {
+                                    int32_t *tokens_out, int32_t *lens_out, wm_mem mem) try {
     WM_MODEL(ctx);
     WM_REQUIRE(m->finalized, WM_ERR_STATE, "model weights not finalised (wm_finalize)");
     WM_REQUIRE(pcm && prompt && tokens_out && lens_out, WM_ERR_INVALID, "null pointer");
@@ -450,4 +463,4 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
         for (int i = 0; i < 3; ++i) ctx->stage_ms[i] += wave_ms[i];  // lanes overlap: slowest lane per stage
     }
     return WM_OK;
-}
+} WM_API_CATCH

@@ -3,7 +3,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <exception>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -35,6 +37,22 @@ void wm_set_error(const char *fmt, ...);
             return (code);                                                                \
         }                                                                                 \
     } while (0)
+
+// Every int-returning entry point of the C ABI is a function-try-block closed by this: no C++ exception (bad_alloc /
+// length_error from a std::vector sized by caller- or file-supplied numbers, ...) ever crosses the FFI.
+#define WM_API_CATCH                                                                      \
+    catch (const std::bad_alloc &) {                                                      \
+        wm_set_error("out of host memory");                                               \
+        return WM_ERR_NOMEM;                                                              \
+    }                                                                                     \
+    catch (const std::exception &e) {                                                     \
+        wm_set_error("internal error: %s", e.what());                                     \
+        return WM_ERR_NOMEM;                                                              \
+    }                                                                                     \
+    catch (...) {                                                                         \
+        wm_set_error("internal error (unknown exception)");                               \
+        return WM_ERR_NOMEM;                                                              \
+    }
 
 // ---------------------------------------------------------------- fixed geometry -----
 // Literals of the reference front end (stft/src/lib.rs:24,26,35-37,50-52,112,116).

@@ -159,3 +159,48 @@ def test_profiler_reports_kernel_families(fe):
     prof = fe.profile()
     fe.profile_enable(False)
     assert prof["logmel_stage1_f32"]["n"] == 1 and prof["logmel_stage1_f32"]["ms"] > 0
+
+
+def test_non_finite_samples_follow_the_reference(fe, oracle_lib):
+    """lib.rs:71-88 on NaN / +Inf input: `x.max(1e-10)` drops NaN (NaN -> 1e-10 -> -10 before
+    the clamp), and the DENSE mel sum of lib.rs:60-69 multiplies every bin by its (mostly zero) weight, so a frame that
+    holds one non-finite sample has non-finite power in every bin and 0 x Inf = NaN in every mel row: the whole frame
+    falls to the log floor, the other frames are untouched and the per-chunk max comes from them."""
+    for bad in (np.nan, np.inf, -np.inf):
+        x = L.synth_chunk(6).astype(np.float64)
+        x[123456] = bad
+        want, _ = oracle_logmel(oracle_lib, x)
+        got = fe.logmel(x, out_dtype=np.float64)[0]
+        assert np.isfinite(want).all() and np.isfinite(got).all(), bad
+        assert np.abs(got - want).max() <= TOL64, (bad, np.abs(got - want).max())
+        got32 = fe.logmel(x.astype(np.float32), out_dtype=np.float32)[0]
+        assert np.abs(got32 - want).max() <= TOL32, bad
+    # the f64 ABI symbol itself
+    x = L.synth_chunk(6).astype(np.float64)
+    x[5] = np.nan          # inside the reflected margin: the mirrored frames are hit too
+    want, _ = oracle_logmel(oracle_lib, x)
+    import openai_whisper_coreml_amd as pkg
+    got = pkg.generateSpectrogram(x).reshape(80, 3000)
+    assert np.abs(got - want).max() <= TOL64
+
+
+def test_generate_spectrogram_from_two_threads(pkg, oracle_lib):
+    """bridge.h:11's symbol is re-entrant in the reference (immutable lazily-initialised state, lib.rs:11-14); here a
+    mutex serialises the shared context.  Two threads, different inputs, each must get its own result."""
+    import threading
+    xs = [L.synth_chunk(50 + i).astype(np.float64) for i in range(2)]
+    want = [oracle_logmel(oracle_lib, x)[0] for x in xs]
+    got = [[None] * 6, [None] * 6]
+
+    def work(t):
+        for i in range(6):
+            got[t][i] = pkg.generateSpectrogram(xs[t]).reshape(80, 3000)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for t in range(2):
+        for i in range(6):
+            assert np.abs(got[t][i] - want[t]).max() <= TOL64, (t, i)

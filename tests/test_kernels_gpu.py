@@ -154,7 +154,7 @@ def test_decode_gemv(ctx, B, N, K, ln):
 
 
 @pytest.mark.parametrize("B,H,T,n_keys,nsplit", [(2, 2, 448, 1, 1), (2, 2, 448, 37, 1), (1, 3, 448, 448, 1),
-                                                 (2, 2, 1500, 1500, 4), (1, 1, 1500, 1500, 3), (8, 20, 1500, 1500, 1),
+                                                 (2, 2, 1500, 1500, 4), (1, 1, 1500, 1500, 2), (8, 20, 1500, 1500, 1),
                                                  (3, 2, 448, 130, 8),
                                                  # nsplit 0 = the decoder's self-attention kernel (4-wave workgroup per pair)
                                                  (2, 2, 448, 1, 0), (2, 3, 448, 37, 0), (1, 3, 448, 128, 0),
@@ -178,6 +178,23 @@ def test_decode_attention(ctx, B, H, T, n_keys, nsplit):
     ref = (w @ tv).reshape(B, H * 64).numpy()
     # head outputs are written as bf16 (they are the out-projection's MFMA operand)
     assert np.abs(out - ref).max() <= 2 ** -8 * max(1.0, np.abs(ref).max())
+
+
+def test_decode_attention_is_bitwise_independent_of_the_split(ctx):
+    """The 8 streams of a (sequence, head) pair may be dealt to 1, 2, 4 or 8 workgroups (few pairs: fill the chip): the
+    head outputs must not change by a single bit, or the tokens would depend on the size of the decode group."""
+    rng = np.random.default_rng(5)
+    B, H, T = 3, 2, 1500
+    q = rng.standard_normal((B, H * 64)).astype(np.float32)
+    k = bf(rng.standard_normal((B, H, T, 64)))
+    v = bf(rng.standard_normal((B, H, T, 64)))
+    outs = []
+    for ns in (1, 2, 4, 8, -1):
+        out = np.zeros((B, H * 64), np.float32)
+        assert ctx.lib.wmdbg_dec_attention(ctx.handle, P(q), P(k), P(v), B, H, T, 1500, ns, P(out)) == 0
+        outs.append(out)
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
 
 
 def test_decode_attention_rejects_bad_split(ctx):
