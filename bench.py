@@ -6,9 +6,9 @@ One "step" = one pass of the hot path over one batch of synthetic 16 kHz audio t
 already resident in HBM (int16 PCM): log-mel front end -> encoder -> cross-attention K/V
 -> KV-cached greedy decode of 224 tokens (n_text_ctx // 2, EOT suppressed so the work is
 fixed) -> tokens on the host.  Steps are independent batches; the engine batches them continuously:
---fuse F (default 12) consecutive batches are decoded as ONE group of F*8 = 96 chunks (the decoder weights are
+--fuse F (default 16) consecutive batches are decoded as ONE group of up to F*8 = 128 chunks (the decoder weights are
 streamed once per group and position), and --inflight S (default 3) groups are kept in flight per GPU on S
-weight-sharing contexts (the decode chain of one group is latency-bound).  The latency of a single batch of 8
+weight-sharing contexts (one group's encoder overlaps the others' decode).  The latency of a single batch of 8
 is reported next to the pipelined throughput.  Everything runs through the C ABI of libwhisper_mi355x.so
 (no torch compute; torch is only used for torch.distributed / RCCL at N > 1).
 
@@ -86,8 +86,8 @@ def cpu_baseline(ctx, dims, pcm16_chunk, prompt):
     """CPU oracle timed on this box's host cores (a reported baseline, not the target):
     C restatement of the Rust front end (1 thread, as the crate is single-threaded) +
     PyTorch fp32 restatement of the model, same synthetic weights pulled back from HBM.
-    BOUNDED sample (~10-30 s): 1 chunk; front end in full; conv stem + the first 2 of the
-    encoder layers; cross-K/V and 2 decode steps (batch 1) of the first 2 decoder layers;
+    BOUNDED sample (~10-30 s): 1 chunk; front end in full; conv stem + the first 4 of the
+    encoder layers; cross-K/V and 8 decode steps (batch 1) of the first 4 decoder layers;
     per-layer times are extrapolated to the full depth and 224 tokens."""
     import subprocess
     import importlib
@@ -107,7 +107,7 @@ def cpu_baseline(ctx, dims, pcm16_chunk, prompt):
     lib.oracle_logmel_batch_f32(x.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(1),
                                 out.ctypes.data_as(ctypes.c_void_p))
     t_fe = time.perf_counter() - t0
-    nl = 2
+    nl = 4
     sub = dict(dims, n_audio_layer=nl, n_text_layer=nl)
     keep = {n: s for n, s, _ in W.tensor_specs(sub)}
     sd = {n: torch.from_numpy(ctx.get_tensor(n, s)) for n, s in keep.items()}
@@ -125,7 +125,7 @@ def cpu_baseline(ctx, dims, pcm16_chunk, prompt):
         torch.nn.functional.linear(xa, sd[p + ".key.weight"])
         torch.nn.functional.linear(xa, sd[p + ".value.weight"], sd[p + ".value.bias"])
     t_xkv = (time.perf_counter() - t0) / nl * dims["n_text_layer"]
-    n_steps = 2
+    n_steps = 8
     t0 = time.perf_counter()
     R.greedy(sd, sub, xa, prompt, n_steps, eot=-1)
     t_dec = time.perf_counter() - t0
@@ -137,8 +137,8 @@ def cpu_baseline(ctx, dims, pcm16_chunk, prompt):
     return {"value": 30.0 / total, "unit": "audio-sec/s", "cores": threads if cores >= threads else cores,
             "kind": "port",
             "sample": "1 chunk on %d host threads (%d usable cores): C front-end restatement (1 thread) %.3f s; torch-fp32 "
-                      "conv stem + 2 encoder layers timed, x%d layers => encoder %.2f s; cross-K/V %.2f s; 2 decode steps of "
-                      "2 decoder layers at batch 1 timed => %.3f s/step, 224 steps extrapolated.  The Rust crate and "
+                      "conv stem + 4 encoder layers timed, x%d layers => encoder %.2f s; cross-K/V %.2f s; 8 decode steps of "
+                      "4 decoder layers at batch 1 timed => %.3f s/step, 224 steps extrapolated.  The Rust crate and "
                       "the CoreML models themselves cannot run here." % (threads, cores, t_fe, dims["n_audio_layer"], t_enc,
                                                                        t_xkv, t_step),
             "decoder_tok_per_s": 1.0 / t_step}
@@ -154,10 +154,13 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=224)
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent batches kept in flight per GPU (each on its own HIP stream / context clone)")
-    ap.add_argument("--fuse", type=int, default=12,
+    ap.add_argument("--fuse", type=int, default=16,
                     help="consecutive steps (batches) decoded together as ONE group of fuse*batch chunks (<= 128): the "
                          "decoder weights are streamed once per group and position")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-batch", action="store_true",
+                    help="skip the one-batch-in-flight latency measurement (profiling runs: keeps every decode launch of the "
+                         "process at the timed group size)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -259,7 +262,7 @@ def main():
 
     # for transparency: the same workload with ONE batch in flight (latency of a single batch of nb chunks)
     single_ms = None
-    if S > 1 or F > 1:
+    if (S > 1 or F > 1) and not args.no_single_batch:
         sync_all()
         t1 = time.perf_counter()
         for _ in range(2):
@@ -267,15 +270,20 @@ def main():
         ctx.sync()
         single_ms = (time.perf_counter() - t1) / 2 * 1e3
 
-    # second pass of the SAME steps with per-launch HIP events on the launch stream
+    # Roofline of the dominant kernel, at the decode-group size the timed region actually ran: a second pass of ONE group
+    # of that size (one lane, eager launches) with every launch bracketed by HIP events on the launch stream.
+    # `profiles/` holds the rocprofv3 --kernel-trace summary of the same single-lane command (profiles/README.md).
     roof = None
     prof = {}
+    grp_steps = max(sharding.plan_groups(args.steps, F, S)) if args.steps > 0 else 1
+    mean_grp_steps = args.steps / max(1, len(sharding.plan_groups(args.steps, F, S)))   # weights stream once per group
+    grp_chunks = nb * grp_steps
     if rank == 0:
         ctx.profile_reset()
         ctx.profile_enable(True)
-        n_prof = min(args.steps, 3)
+        n_prof = 1 if grp_chunks > 16 else min(args.steps, 3)
         for _ in range(n_prof):
-            ctx.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE, pcm_dtype=B.WM_I16, B=nb)
+            ctx.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE, pcm_dtype=B.WM_I16, B=grp_chunks)
         prof = ctx.profile()
         ctx.profile_enable(False)
         ev_over = ctx.profile_overhead_us()      # cost of the two hipEventRecord calls themselves
@@ -286,26 +294,23 @@ def main():
             pass
         if prof:
             dom = max(prof, key=lambda k: prof[k]["ms"])
-            kind, work = algorithmic_work(dom, dims, nb)
+            kind, work = algorithmic_work(dom, dims, grp_chunks)
             raw_us = prof[dom]["ms"] / prof[dom]["n"] * 1e3
             avg_s = max(raw_us - ev_over, 1e-3) * 1e-6
-            # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE pass (profiles/), only
-            # valid for the geometry it was taken on (large-v2, B = 8)
-            traffic = None
-            if args.model == "large-v2" and nb == 8 and dom in traffic_db:
-                traffic = traffic_db[dom]["hbm_read_bytes_per_launch"]
+            # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE pass (profiles/), valid only for the
+            # geometry it was taken on: keyed "<family>@<model>:B<group chunks>"
+            t = traffic_db.get("%s@%s:B%d" % (dom, args.model, grp_chunks))
+            traffic = t["hbm_read_bytes_per_launch"] if t else None
+            common = {"kernel": dom, "group_chunks": grp_chunks, "traffic": traffic, "avg_us": avg_s * 1e6,
+                      "avg_us_events_raw": raw_us, "event_overhead_us": ev_over, "launches": prof[dom]["n"]}
             if kind == "hbm":
                 ach = work / avg_s / 1e9
-                roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_us": avg_s * 1e6,
-                        "avg_us_events_raw": raw_us, "event_overhead_us": ev_over,
-                        "alg_bytes_per_launch": work, "launches": prof[dom]["n"]}
+                roof = dict(common, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                            alg_bytes_per_launch=work)
             elif kind == "mfma":
                 ach = work / avg_s / 1e12
-                roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TF,
-                        "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TF, "traffic": traffic,
-                        "avg_us": avg_s * 1e6, "avg_us_events_raw": raw_us, "event_overhead_us": ev_over,
-                        "alg_flops_per_launch": work, "launches": prof[dom]["n"]}
+                roof = dict(common, bound="mfma", achieved=ach, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
+                            frac=ach / MFMA_BF16_PEAK_TF, alg_flops_per_launch=work)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -326,7 +331,7 @@ def main():
         xkv_flops = nb * L * 4.0 * 1500 * d * d
         t_mean = (len(prompt) + max_new) / 2.0
         # per step (= nb chunks): the weights are streamed once per decode group of F steps
-        dec_bytes = dec_steps * (2.0 * (L * 14 * d * d + V * d) / F + nb * L * 2 * 1500 * d * 2 + nb * L * 2 * t_mean * d * 2)
+        dec_bytes = dec_steps * (2.0 * (L * 14 * d * d + V * d) / mean_grp_steps + nb * L * 2 * 1500 * d * 2 + nb * L * 2 * t_mean * d * 2)
         out = {}
         if stage_s[0] > 0:
             a = fe_bytes / stage_s[0] / 1e9
@@ -340,6 +345,20 @@ def main():
             out["decode"] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
                              "bytes_per_position": dec_bytes / dec_steps}
         return out
+
+    def step_roofline(step_s, dec_steps):
+        """Whole step against the sum of its stages' rooflines: HBM time of the front end and of the decode bytes at
+        8 TB/s plus MFMA time of the encoder + cross-K/V flops at 2.5 PFLOP/s, over the measured wall time per step."""
+        d, L, V = dims["n_text_state"], dims["n_text_layer"], dims["n_vocab"]
+        da, La, nm = dims["n_audio_state"], dims["n_audio_layer"], dims["n_mels"]
+        fe_bytes = nb * (480000 * 2 + nm * 3000 * 4)
+        flops = nb * (2.0 * 3000 * da * nm * 3 + 2.0 * 1500 * da * da * 3
+                      + La * (8.0 * 1500 * da * da + 4.0 * 1500 * 1500 * da + 16.0 * 1500 * da * da)) + nb * L * 4.0 * 1500 * d * d
+        t_mean = (len(prompt) + max_new) / 2.0
+        dec_bytes = dec_steps * (2.0 * (L * 14 * d * d + V * d) / mean_grp_steps + nb * L * 2 * 1500 * d * 2 + nb * L * 2 * t_mean * d * 2)
+        bound_s = (fe_bytes + dec_bytes) / (HBM_PEAK_GBS * 1e9) + flops / (MFMA_BF16_PEAK_TF * 1e12)
+        return {"bound_ms": bound_s * 1e3, "measured_ms": step_s * 1e3, "frac": bound_s / step_s,
+                "hbm_bytes": fe_bytes + dec_bytes, "mfma_flops": flops}
 
     if rank == 0:
         total_audio = 30.0 * nb * world * args.steps
@@ -358,23 +377,26 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "whisper-%s geometry, random-init weights, batches of %d x 30 s int16 chunks resident "
                                    "in HBM, greedy %d new tokens (EOT suppressed), prompt %d tokens; a step = one batch; "
-                                   "%d consecutive batches are decoded as one group of %d chunks, %d groups in flight per GPU "
-                                   "(one HIP stream + KV cache each, weights shared)"
-                                   % (args.model, nb, max_new, len(prompt), F, nb * F, S),
-                       "chunks_per_gpu": nb, "new_tokens": max_new, "decode_group_chunks": nb * F,
+                                   "up to %d consecutive batches are decoded as one group (largest: %d chunks), %d groups in "
+                                   "flight per GPU (one HIP stream + KV cache each, weights shared)"
+                                   % (args.model, nb, max_new, len(prompt), F, grp_chunks, S),
+                       "chunks_per_gpu": nb, "new_tokens": max_new, "decode_group_chunks": grp_chunks,
+                       "decode_groups": sharding.plan_groups(args.steps, F, S),
                        "inflight_batches_per_gpu": S * F, "parallelism": "chunk-dp%d" % world},
             "rtf": dt / total_audio,
             "decoder_tok_per_s": (S * nb * world * max_new) / max(stage_s[2], 1e-9),   # S pipelines decode concurrently
             "tok_per_s_end_to_end": (nb * world * max_new * args.steps) / dt,
             "inflight_batches_per_gpu": S * F,
             "tokens_consistent_across_groups": tokens_consistent,
+            # the literal BASELINE.json configs[3] figure: ONE batch of %d chunks in flight, nothing else on the GPU
+            "value_batch8": (30.0 * nb / (single_ms * 1e-3)) if single_ms else None,
             "single_batch_latency_ms": single_ms,
-            "value_one_batch_in_flight": (30.0 * nb / (single_ms * 1e-3)) if single_ms else None,
             "decoder_ms_per_step": stage_s[2] * 1e3 / dec_steps,
             "stage_ms": {"frontend": stage_s[0] * 1e3, "encoder_xkv": stage_s[1] * 1e3, "decode": stage_s[2] * 1e3},
             "roofline": roof,
             "stage_roofline": stage_rooflines(stage_s / S, dec_steps),   # S pipelines overlap: per-step share of wall time
-            "roofline_note": "mean launch duration from per-launch HIP events (hipEventRecord on the launch stream) in a second pass of the same steps, minus the event-bracketing bias calibrated on a kernel of known device-clock duration; traffic = 2 x FETCH_SIZE from a separate rocprofv3 --pmc pass (profiles/)",
+            "step_roofline": step_roofline(dt / args.steps, dec_steps),
+            "roofline_note": "dominant kernel family of ONE decode group of the size the timed region ran (single lane, eager launches): mean launch duration from per-launch HIP events on the launch stream minus the event-bracketing bias calibrated on a kernel of known device-clock duration; the rocprofv3 --kernel-trace summary of the same single-lane command is in profiles/; traffic = 2 x FETCH_SIZE from a separate rocprofv3 --pmc pass (profiles/pmc_traffic.json), null when no pass exists for this geometry",
             "cpu_baseline": cpu,
             "kernel_families": fams,
         }

@@ -175,6 +175,44 @@ WM_API int wm_set_suppress(wm_ctx *ctx, const int32_t *suppress, int n, const in
 WM_API int wm_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t timestamp_begin, int32_t eot,
                            int32_t max_initial_timestamp_index);
 
+/* ------------------------------------------------- all GPUs of the node, one host process --- */
+/* the Swift host dlopens ONE library in ONE process; wm_multi drives n GPUs from it.  Weights are
+ * replicated (one wm_ctx per device: fetch each with wm_multi_device_ctx and fill it with wm_load_weights /
+ * wm_set_tensor / wm_init_synthetic + wm_finalize, exactly as a single context), a call's chunks are cut into contiguous
+ * blocks -- rank r owns [r ceil(B/n), min(B, (r+1) ceil(B/n))) -- each block runs its whole path (front end -> encoder
+ * -> greedy decode) on its own GPU from its own host thread, and the only exchange is ONE fixed-stride all-gather of
+ * int32 [ceil(B/n)][1 + max_new] (length, tokens) per rank over RCCL / xGMI (ncclCommInitAll).  n = 1 is valid.
+ *   devices    : n distinct HIP device ordinals;
+ *   pcm        : HOST [B][480000] samples; tokens_out i32 [B][max_new], lens_out i32 [B] (host), as wm_transcribe_greedy. */
+typedef struct wm_multi wm_multi;
+WM_API int wm_multi_create(const wm_dims *dims, const int *devices, int n, wm_multi **out);
+WM_API void wm_multi_destroy(wm_multi *m);
+WM_API int wm_multi_size(const wm_multi *m);
+WM_API int wm_multi_device_ctx(wm_multi *m, int rank, wm_ctx **out);
+WM_API int wm_multi_transcribe_greedy(wm_multi *m, const void *pcm, wm_dtype pcm_dtype, int B, const int32_t *prompt,
+                               int n_prompt, int max_new, int32_t eot, int32_t *tokens_out, int32_t *lens_out);
+/* Host-only pieces of the above (usable without a GPU; also what the CPU tests pin): the block partition, and the
+ * fixed-stride payload [per][1 + max_new] = (length, tokens) each rank contributes to the all-gather. */
+WM_API int wm_multi_partition(int n_chunks, int world_size, int rank, int *lo, int *hi);
+WM_API int wm_multi_pack_tokens(const int32_t *tokens, const int32_t *lens, int n_local, int per, int max_new,
+                         int32_t *payload);
+WM_API int wm_multi_unpack_tokens(const int32_t *gathered, int world_size, int per, int max_new, int n_chunks,
+                           int32_t *tokens_out, int32_t *lens_out);
+
+/* -------------------------------------------------------------- ids -> text (host only) --- */
+/* GPT-2 byte-level BPE de-tokenizer for the ids wm_transcribe_greedy returns (the reference prints
+ * a language code and has no tokenizer, Whisper.swift:37-39).  vocab_json_path: the tokenizer's vocab.json
+ * ({"piece": id, ...}, pieces over GPT-2's byte alphabet) -- supplied by the host, no vocabulary ships with the library.
+ * wm_detokenize: UTF-8 text of ids[0..n): ids without a piece (special tokens, timestamps) are skipped
+ * (skip_special != 0) or written as <|id|>.  Writes at most cap - 1 bytes + NUL; *needed (nullable) = bytes required
+ * including the NUL, so cap = 0 sizes the buffer.  No GPU involved. */
+typedef struct wm_vocab wm_vocab;
+WM_API int wm_vocab_load(const char *vocab_json_path, wm_vocab **out);
+WM_API void wm_vocab_free(wm_vocab *v);
+WM_API int wm_vocab_size(const wm_vocab *v);
+WM_API int wm_detokenize(const wm_vocab *v, const int32_t *ids, int n, int skip_special, char *buf, size_t cap,
+                  size_t *needed);
+
 /* ------------------------------------------------------------ device memory helpers --- */
 /* For callers that keep inputs resident in HBM (bench.py; a Swift host would use them to
  * avoid the 5.7 MB/chunk PCIe round trip of the reference ABI). */

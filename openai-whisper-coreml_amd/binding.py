@@ -118,6 +118,16 @@ def load_library(path=None):
         "wm_profile_json": [vp, ctypes.c_char_p, sz],
         "wm_profile_overhead_us": [vp, vp],
         "wm_last_stage_ms": [vp, vp],
+        "wm_vocab_load": [ctypes.c_char_p, pp],
+        "wm_vocab_size": [vp],
+        "wm_detokenize": [vp, vp, ip, ip, vp, sz, vp],
+        "wm_multi_create": [ctypes.POINTER(wm_dims), vp, ip, pp],
+        "wm_multi_size": [vp],
+        "wm_multi_device_ctx": [vp, ip, pp],
+        "wm_multi_transcribe_greedy": [vp, vp, ip, ip, vp, ip, ip, ctypes.c_int32, vp, vp],
+        "wm_multi_partition": [ip, ip, ip, vp, vp],
+        "wm_multi_pack_tokens": [vp, vp, ip, ip, ip, vp],
+        "wm_multi_unpack_tokens": [vp, ip, ip, ip, ip, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -125,6 +135,10 @@ def load_library(path=None):
         fn.restype = ctypes.c_int
     lib.wm_destroy.argtypes = [vp]
     lib.wm_destroy.restype = None
+    lib.wm_multi_destroy.argtypes = [vp]
+    lib.wm_multi_destroy.restype = None
+    lib.wm_vocab_free.argtypes = [vp]
+    lib.wm_vocab_free.restype = None
     if path is None:
         _lib = lib
     return lib
@@ -359,6 +373,91 @@ class Context:
                                                        len(prompt), max_new, eot, _ptr(toks),
                                                        _ptr(lens), mem))
         return toks, lens
+
+
+class Vocab:
+    """wm_vocab: GPT-2 byte-level BPE de-tokenizer over a host-supplied vocab.json (ids -> UTF-8 text, no GPU)."""
+
+    def __init__(self, vocab_json_path):
+        self.lib = load_library()
+        self.handle = ctypes.c_void_p()
+        _check(self.lib, self.lib.wm_vocab_load(str(vocab_json_path).encode(), ctypes.byref(self.handle)))
+
+    def __len__(self):
+        return int(self.lib.wm_vocab_size(self.handle))
+
+    def decode(self, ids, skip_special=True):
+        ids = np.ascontiguousarray(ids, dtype=np.int32).reshape(-1)
+        need = ctypes.c_size_t()
+        _check(self.lib, self.lib.wm_detokenize(self.handle, _ptr(ids), len(ids), 1 if skip_special else 0, None, 0,
+                                                ctypes.byref(need)))
+        buf = ctypes.create_string_buffer(need.value)
+        _check(self.lib, self.lib.wm_detokenize(self.handle, _ptr(ids), len(ids), 1 if skip_special else 0, buf,
+                                                need.value, None))
+        return buf.raw[:need.value - 1].decode("utf-8", "replace")
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            self.lib.wm_vocab_free(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiContext:
+    """wm_multi: every listed GPU of the node from ONE process (include/whisper_mi355x.h): weights replicated, chunks
+    block-partitioned, one RCCL all-gather of the token streams."""
+
+    def __init__(self, dims, devices=(0,)):
+        self.lib = load_library()
+        self.handle = ctypes.c_void_p()
+        d = wm_dims(**dims) if isinstance(dims, dict) else dims
+        devs = np.ascontiguousarray(list(devices), dtype=np.int32)
+        _check(self.lib, self.lib.wm_multi_create(ctypes.byref(d), _ptr(devs), len(devs), ctypes.byref(self.handle)))
+        self.dims = d.as_dict()
+        self.n = int(self.lib.wm_multi_size(self.handle))
+
+    def device_ctx(self, rank):
+        """Borrowed Context of one device (owned by the MultiContext: do not close it)."""
+        c = Context.__new__(Context)
+        c.lib = self.lib
+        c.handle = ctypes.c_void_p()
+        c.dims = dict(self.dims)
+        _check(self.lib, self.lib.wm_multi_device_ctx(self.handle, int(rank), ctypes.byref(c.handle)))
+        c.close = lambda: None
+        c._owner = self
+        return c
+
+    def init_synthetic(self, seed):
+        for r in range(self.n):
+            c = self.device_ctx(r)
+            c.init_synthetic(seed)
+            c.finalize()
+
+    def transcribe_greedy(self, pcm, prompt, max_new, eot=-1):
+        pcm = np.ascontiguousarray(pcm)
+        prompt = np.ascontiguousarray(prompt, dtype=np.int32)
+        Bn = pcm.shape[0]
+        toks = np.empty((Bn, max_new), dtype=np.int32)
+        lens = np.empty(Bn, dtype=np.int32)
+        _check(self.lib, self.lib.wm_multi_transcribe_greedy(self.handle, _ptr(pcm), _DTYPES[pcm.dtype], Bn, _ptr(prompt),
+                                                             len(prompt), max_new, eot, _ptr(toks), _ptr(lens)))
+        return toks, lens
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            self.lib.wm_multi_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Whisper:

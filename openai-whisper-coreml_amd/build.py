@@ -74,7 +74,7 @@ def build(force=False, verbose=True):
     for lib, members, vmap in ((LIB, prod, maps["product"]), (DBG_LIB, objs, maps["debug"])):
         if changed or not os.path.exists(lib):
             cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + members + [
-                "-Wl,-rpath,/opt/rocm/lib", "-Wl,--version-script=" + vmap, "-lpthread"]
+                "-Wl,-rpath,/opt/rocm/lib", "-Wl,--version-script=" + vmap, "-L/opt/rocm/lib", "-lrccl", "-lpthread"]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
@@ -85,23 +85,27 @@ def build(force=False, verbose=True):
     return LIB
 
 
-def build_host(force=False, verbose=True):
-    """C++ host harness (the stand-in for the Swift caller)."""
-    src = os.path.join(HERE, "host", "lid_main.cpp")
+def build_host(force=False, verbose=True, name="lid_main"):
+    """C++ host harnesses (stand-ins for the Swift caller): lid_main = the reference's language-ID
+    flow on one GPU, multi_main = all GPUs of the node from one dlopen-only process."""
+    src = os.path.join(HERE, "host", name + ".cpp")
+    exe = os.path.join(HERE, "host", name)
     if not os.path.exists(src):
         return None
-    if (not force and os.path.exists(HOST_BIN)
-            and os.path.getmtime(HOST_BIN) >= os.path.getmtime(src)):
-        return HOST_BIN
-    cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", HOST_BIN, "-ldl"]
+    hdr = os.path.join(ROOT, "include", "whisper_mi355x.h")
+    if (not force and os.path.exists(exe) and os.path.getmtime(exe) >= os.path.getmtime(src)
+            and os.path.getmtime(exe) >= os.path.getmtime(hdr)):
+        return exe
+    cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), src, "-o", exe, "-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("host build failed:\n%s\n%s" % (r.stdout, r.stderr))
     if verbose:
-        print("built", HOST_BIN)
-    return HOST_BIN
+        print("built", exe)
+    return exe
 
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     build_host(force="--force" in sys.argv)
+    build_host(force="--force" in sys.argv, name="multi_main")

@@ -112,13 +112,21 @@ constexpr int VS_STRIDE = 136;  // bytes per V^T row in LDS (128 + 8 pad): confl
 __global__ __launch_bounds__(256, 4) void enc_attn_kernel(const bf16_t *__restrict__ qk,
                                                           const bf16_t *__restrict__ vt,
                                                           bf16_t *__restrict__ att, int H, int S,
-                                                          int S_pad, int d) {
+                                                          int S_pad, int d, int n_q, int n_bh) {
     __shared__ __attribute__((aligned(16))) char ks[2][64 * KS_STRIDE];
     __shared__ __attribute__((aligned(16))) char vs[2][64 * VS_STRIDE];
-    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    // XCD-aware workgroup map.  The n_q query blocks of one (chunk, head) pair all stream the same 384 KB of K / V^T;
+    // dispatch places workgroup w on XCD w % 8 (observed, not guaranteed: a wrong guess only costs speed), and each XCD
+    // has a private L2 -- so the pairs are dealt to the XCDs (pair % 8) and the n_q blocks of a pair are CONSECUTIVE
+    // workgroups of that XCD: K / V^T is fetched from HBM once per pair instead of once per XCD that happens to hold one
+    // of its query blocks (round 1, grid (n_q, pairs): 537 MB fetched per launch for 93 MB of Q + K + V^T).
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int bh = (j / n_q) * 8 + xcd, qblk = j % n_q;
+    if (bh >= n_bh) return;  // workgroup-uniform (pair count padded to a multiple of 8)
+    const int b = bh / H, h = bh % H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane & 31, hf = lane >> 5;
-    const int q = blockIdx.x * 128 + wave * 32 + ql;
+    const int q = qblk * 128 + wave * 32 + ql;
     const int qc = q < S ? q : S - 1;
     const long ld = 2L * d;
     const float c = 0.125f * 1.44269504088896340736f;  // hd^-0.5 * log2(e), hd = 64
@@ -303,8 +311,9 @@ int wm_enc_attention(wm_ctx *ctx, const bf16_t *qk, const bf16_t *vt, bf16_t *at
     WM_REQUIRE(d == H * 64, WM_ERR_INVALID, "attention: head_dim must be 64 (d=%d, H=%d)", d, H);
     WM_REQUIRE(S_pad % 64 == 0 && S_pad >= S, WM_ERR_INVALID, "attention: bad S_pad");
     WmProfScope ps(&ctx->prof, "enc_attention", ctx->stream);
-    dim3 grid((S + 127) / 128, B * H);
-    enc_attn_kernel<<<grid, 256, 0, ctx->stream>>>(qk, vt, att, H, S, S_pad, d);
+    const int n_q = (S + 127) / 128, n_bh = B * H;
+    const int grid = (n_bh + 7) / 8 * 8 * n_q;
+    enc_attn_kernel<<<grid, 256, 0, ctx->stream>>>(qk, vt, att, H, S, S_pad, d, n_q, n_bh);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

@@ -1,0 +1,197 @@
+// multi.cpp -- the 8-GPU split behind the C ABI (SURVEY.md 8b `device_ids[], n`, 8e): ONE host process that dlopens the
+// library drives every GPU of the node.  Independent 30 s chunks are the natural shard of the path (the front end's only
+// reduction is per chunk, stft/src/lib.rs:82-88; the reference never conditions one window on another,
+// Whisper.swift:33-40), so
+//   * weights are replicated: one wm_ctx per device (fill them through wm_multi_device_ctx + the usual weight calls);
+//   * a call's chunks are cut into contiguous blocks, rank r owns [r ceil(N/R), min(N, (r+1) ceil(N/R)));
+//   * one host thread per GPU runs the whole path of its block (front end -> encoder -> cross-K/V -> greedy decode);
+//   * the ONLY exchange is one fixed-stride all-gather of int32 [ceil(N/R)][1 + max_new] (length, tokens) per rank over
+//     RCCL (ncclCommInitAll: single process, xGMI between the GPUs) -- ~13.5 KB per rank for an hour of audio, latency-
+//     bound; every rank ends with every stream, rank 0's copy is handed to the caller.
+// bench.py --gpus N uses the one-process-per-GPU launch the driver prescribes (torch.distributed over the same RCCL);
+// this is the same partition and the same collective for a dlopen-only host (host/multi_main.cpp).
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "model.h"
+
+struct wm_multi {
+    std::vector<wm_ctx *> ctx;
+    std::vector<int> dev;
+    std::vector<ncclComm_t> comm;
+    std::vector<int32_t *> d_send, d_recv;
+    size_t cap_rows = 0, cap_stride = 0;
+};
+
+extern "C" int wm_multi_partition(int n_chunks, int world_size, int rank, int *lo, int *hi) try {
+    WM_REQUIRE(lo && hi && n_chunks >= 0 && world_size >= 1 && rank >= 0 && rank < world_size, WM_ERR_INVALID,
+               "partition: bad arguments");
+    const int per = (n_chunks + world_size - 1) / world_size;
+    *lo = rank * per < n_chunks ? rank * per : n_chunks;
+    *hi = (rank + 1) * per < n_chunks ? (rank + 1) * per : n_chunks;
+    return WM_OK;
+} WM_API_CATCH
+
+// Host-side packing of the fixed-stride gather payload: row i of a rank's block = [len, tok_0 .. tok_{max_new-1}];
+// rows past the block are zero.  wm_multi_unpack_tokens inverts it over the concatenation of all ranks' payloads.
+extern "C" int wm_multi_pack_tokens(const int32_t *tokens, const int32_t *lens, int n_local, int per, int max_new,
+                                    int32_t *payload) try {
+    WM_REQUIRE(payload && n_local >= 0 && n_local <= per && max_new >= 0 && (n_local == 0 || (tokens && lens)),
+               WM_ERR_INVALID, "pack_tokens: bad arguments");
+    const size_t stride = 1 + (size_t)max_new;
+    memset(payload, 0, (size_t)per * stride * sizeof(int32_t));
+    for (int i = 0; i < n_local; ++i) {
+        payload[i * stride] = lens[i];
+        memcpy(payload + i * stride + 1, tokens + (size_t)i * max_new, (size_t)max_new * sizeof(int32_t));
+    }
+    return WM_OK;
+} WM_API_CATCH
+
+extern "C" int wm_multi_unpack_tokens(const int32_t *gathered, int world_size, int per, int max_new, int n_chunks,
+                                      int32_t *tokens_out, int32_t *lens_out) try {
+    WM_REQUIRE(gathered && tokens_out && lens_out && world_size >= 1 && per >= 0 && n_chunks >= 0 &&
+                   (long)n_chunks <= (long)world_size * per, WM_ERR_INVALID, "unpack_tokens: bad arguments");
+    const size_t stride = 1 + (size_t)max_new;
+    for (int c = 0; c < n_chunks; ++c) {  // rank r's block starts at row r * per of the gathered buffer == chunk r * per
+        lens_out[c] = gathered[c * stride];
+        memcpy(tokens_out + (size_t)c * max_new, gathered + c * stride + 1, (size_t)max_new * sizeof(int32_t));
+    }
+    return WM_OK;
+} WM_API_CATCH
+
+extern "C" int wm_multi_create(const wm_dims *dims, const int *devices, int n, wm_multi **out) try {
+    WM_REQUIRE(dims && devices && out && n >= 1 && n <= 64, WM_ERR_INVALID, "multi_create: bad arguments");
+    *out = nullptr;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j) WM_REQUIRE(devices[i] != devices[j], WM_ERR_INVALID, "multi_create: device %d listed twice", devices[i]);
+    wm_multi *m = new wm_multi();
+    m->dev.assign(devices, devices + n);
+    int st = WM_OK;
+    for (int i = 0; i < n && st == WM_OK; ++i) {
+        wm_ctx *c = nullptr;
+        st = wm_create(dims, devices[i], &c);
+        if (st == WM_OK) m->ctx.push_back(c);
+    }
+    if (st == WM_OK) {
+        m->comm.resize(n);
+        const ncclResult_t r = ncclCommInitAll(m->comm.data(), n, m->dev.data());
+        if (r != ncclSuccess) {
+            wm_set_error("ncclCommInitAll over %d device(s) failed: %s", n, ncclGetErrorString(r));
+            m->comm.clear();
+            st = WM_ERR_HIP;
+        }
+    }
+    if (st != WM_OK) {
+        const std::string keep = wm_last_error();
+        wm_multi_destroy(m);
+        wm_set_error("%s", keep.c_str());
+        return st;
+    }
+    m->d_send.assign(n, nullptr);
+    m->d_recv.assign(n, nullptr);
+    *out = m;
+    return WM_OK;
+} WM_API_CATCH
+
+extern "C" void wm_multi_destroy(wm_multi *m) {
+    if (!m) return;
+    for (size_t i = 0; i < m->ctx.size(); ++i) {
+        (void)hipSetDevice(m->dev[i]);
+        if (i < m->d_send.size() && m->d_send[i]) (void)hipFree(m->d_send[i]);
+        if (i < m->d_recv.size() && m->d_recv[i]) (void)hipFree(m->d_recv[i]);
+    }
+    for (ncclComm_t c : m->comm) (void)ncclCommDestroy(c);
+    for (wm_ctx *c : m->ctx) wm_destroy(c);
+    delete m;
+}
+
+extern "C" int wm_multi_size(const wm_multi *m) { return m ? (int)m->ctx.size() : 0; }
+
+extern "C" int wm_multi_device_ctx(wm_multi *m, int rank, wm_ctx **out) try {
+    WM_REQUIRE(m && out && rank >= 0 && rank < (int)m->ctx.size(), WM_ERR_INVALID, "multi_device_ctx: bad rank");
+    *out = m->ctx[rank];
+    return WM_OK;
+} WM_API_CATCH
+
+static int ensure_gather_buffers(wm_multi *m, size_t per, size_t stride) {
+    const size_t R = m->ctx.size();
+    if (per * stride <= m->cap_rows * m->cap_stride && m->d_send[0]) return WM_OK;
+    for (size_t r = 0; r < R; ++r) {
+        WM_HIP(hipSetDevice(m->dev[r]));
+        if (m->d_send[r]) WM_HIP(hipFree(m->d_send[r]));
+        if (m->d_recv[r]) WM_HIP(hipFree(m->d_recv[r]));
+        m->d_send[r] = m->d_recv[r] = nullptr;
+        WM_HIP(hipMalloc((void **)&m->d_send[r], per * stride * sizeof(int32_t) + 256));
+        WM_HIP(hipMalloc((void **)&m->d_recv[r], R * per * stride * sizeof(int32_t) + 256));
+    }
+    m->cap_rows = per;
+    m->cap_stride = stride;
+    return WM_OK;
+}
+
+extern "C" int wm_multi_transcribe_greedy(wm_multi *m, const void *pcm, wm_dtype pcm_dtype, int B, const int32_t *prompt,
+                                          int n_prompt, int max_new, int32_t eot, int32_t *tokens_out, int32_t *lens_out) try {
+    WM_REQUIRE(m && pcm && prompt && tokens_out && lens_out && B >= 1 && max_new >= 1, WM_ERR_INVALID,
+               "multi_transcribe_greedy: bad arguments");
+    WM_REQUIRE(pcm_dtype == WM_I16 || pcm_dtype == WM_F32 || pcm_dtype == WM_F64, WM_ERR_INVALID, "bad pcm dtype");
+    const int R = (int)m->ctx.size();
+    const int per = (B + R - 1) / R;
+    const size_t stride = 1 + (size_t)max_new;
+    const size_t elem = pcm_dtype == WM_I16 ? 2 : pcm_dtype == WM_F32 ? 4 : 8;
+    WM_TRY(ensure_gather_buffers(m, (size_t)per, stride));
+    // ---- one host thread per GPU: the whole path of its block of chunks
+    std::vector<int> status(R, WM_OK);
+    std::vector<std::string> errs(R);
+    std::vector<std::vector<int32_t>> payload(R, std::vector<int32_t>((size_t)per * stride, 0));
+    std::vector<std::thread> th;
+    for (int r = 0; r < R; ++r) {
+        th.emplace_back([&, r] {
+            int lo = 0, hi = 0;
+            (void)wm_multi_partition(B, R, r, &lo, &hi);
+            const int n_local = hi - lo;
+            std::vector<int32_t> tok((size_t)(n_local > 0 ? n_local : 1) * max_new), len(n_local > 0 ? n_local : 1);
+            int st = WM_OK;
+            if (n_local > 0)
+                st = wm_transcribe_greedy(m->ctx[r], (const char *)pcm + (size_t)lo * WM_N_SAMPLES * elem, pcm_dtype, n_local,
+                                          prompt, n_prompt, max_new, eot, tok.data(), len.data(), WM_MEM_HOST);
+            if (st == WM_OK) st = wm_multi_pack_tokens(tok.data(), len.data(), n_local, per, max_new, payload[r].data());
+            if (st == WM_OK) {
+                if (hipSetDevice(m->dev[r]) != hipSuccess ||
+                    hipMemcpyAsync(m->d_send[r], payload[r].data(), payload[r].size() * sizeof(int32_t), hipMemcpyHostToDevice,
+                                   m->ctx[r]->stream) != hipSuccess ||
+                    hipStreamSynchronize(m->ctx[r]->stream) != hipSuccess) {
+                    wm_set_error("rank %d: staging the token payload failed", r);
+                    st = WM_ERR_HIP;
+                }
+            }
+            status[r] = st;
+            if (st != WM_OK) errs[r] = wm_last_error();  // thread-local: hand it to the caller's thread
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int r = 0; r < R; ++r)
+        if (status[r] != WM_OK) {
+            wm_set_error("rank %d (device %d): %s", r, m->dev[r], errs[r].c_str());
+            return status[r];
+        }
+    // ---- the one collective of the job: fixed-stride all-gather of the token streams (RCCL over xGMI)
+    ncclResult_t nr = ncclGroupStart();
+    for (int r = 0; r < R && nr == ncclSuccess; ++r)
+        nr = ncclAllGather(m->d_send[r], m->d_recv[r], (size_t)per * stride, ncclInt32, m->comm[r], m->ctx[r]->stream);
+    if (nr == ncclSuccess) nr = ncclGroupEnd();
+    else (void)ncclGroupEnd();
+    WM_REQUIRE(nr == ncclSuccess, WM_ERR_HIP, "ncclAllGather failed: %s", ncclGetErrorString(nr));
+    std::vector<int32_t> all((size_t)R * per * stride);
+    WM_HIP(hipSetDevice(m->dev[0]));
+    WM_HIP(hipMemcpyAsync(all.data(), m->d_recv[0], all.size() * sizeof(int32_t), hipMemcpyDeviceToHost, m->ctx[0]->stream));
+    WM_HIP(hipStreamSynchronize(m->ctx[0]->stream));
+    for (int r = 1; r < R; ++r) {  // every rank received every stream: drain the others' streams too
+        WM_HIP(hipSetDevice(m->dev[r]));
+        WM_HIP(hipStreamSynchronize(m->ctx[r]->stream));
+    }
+    return wm_multi_unpack_tokens(all.data(), R, per, max_new, B, tokens_out, lens_out);
+} WM_API_CATCH

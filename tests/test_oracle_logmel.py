@@ -106,3 +106,28 @@ def test_batch_entry_matches_single(oracle_lib):
     for i in range(2):
         y, _ = oracle_logmel(oracle_lib, x[i])
         assert np.array_equal(out[i], y)
+
+
+def test_kat5_f64_restatement_vs_openai_whisper_f32_formulation(oracle_lib, m80):
+    """KAT-5: the oracle restates the Rust crate (f64, explicit framing, 3000 frames); openai-whisper --
+    whose mel_filters.npz the reference embeds (export_m80.py:4-5) and whose log-mel the exported encoder was trained
+    on -- computes the same quantity with an f32 `torch.stft` (hann 400, hop 160, center / reflect, last frame dropped)
+    [3p, restated here from whisper/audio.py].  Two independent formulations, f64 vs f32 arithmetic: max-abs 1.49e-6 in
+    the survey probe, 3.4e-6 on these chunks; gate 1e-5 (an index, frame-count, padding or clamp disagreement shows up as
+    >= 1e-2).  The f32 GPU path is gated at 1e-4 against the same oracle (test_frontend_gpu)."""
+    import torch
+    for seed in (0, 1):
+        x = L.synth_chunk(seed)
+        want, _ = oracle_logmel(oracle_lib, x)
+        audio = torch.from_numpy(np.asarray(x, np.float32))
+        window = torch.hann_window(400)
+        stft = torch.stft(audio, 400, 160, window=window, return_complex=True)     # center=True, pad_mode="reflect"
+        magnitudes = stft[..., :-1].abs() ** 2                                     # 3001 -> 3000 frames
+        mel_spec = torch.from_numpy(m80) @ magnitudes
+        log_spec = torch.clamp(mel_spec, min=1e-10).log10()
+        log_spec = torch.maximum(log_spec, log_spec.max() - 8.0)
+        log_spec = (log_spec + 4.0) / 4.0
+        got = log_spec.numpy().astype(np.float64)
+        assert got.shape == (80, 3000)
+        err = np.abs(got - want).max()
+        assert err <= 1e-5, err

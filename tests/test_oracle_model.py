@@ -151,3 +151,64 @@ def test_flat_weight_file_roundtrip(tmp_path):
     W.save_flat(p, dims, sd)
     d2, sd2 = W.load_flat(p)
     assert d2 == dims and set(sd2) == set(sd) and all(np.array_equal(sd[k], sd2[k]) for k in sd)
+
+
+def test_against_transformers_whisper_at_full_tiny_en_dims():
+    """The same cross-check at a REAL checkpoint geometry (tiny.en: d 384, 6 heads, 4 + 4 layers, vocab 51864, 37.8 M
+    parameters), not only the d = 128 test model: encoder output and decoder logits of the oracle vs `transformers`'
+    independent Whisper implementation on identical (synthetic) weights."""
+    from transformers import WhisperConfig, WhisperModel
+    dims = dict(n_mels=80, n_audio_ctx=1500, n_audio_state=384, n_audio_head=6, n_audio_layer=4,
+                n_vocab=51864, n_text_ctx=448, n_text_state=384, n_text_head=6, n_text_layer=4)
+    sd_np = W.synthetic_state_dict(dims, 5)
+    rng = np.random.default_rng(5)
+    for k in sd_np:
+        if "ln" in k and k.endswith("weight"):
+            sd_np[k] = (1 + 0.1 * rng.standard_normal(sd_np[k].shape)).astype(np.float32)
+        if "ln" in k and k.endswith("bias"):
+            sd_np[k] = (0.1 * rng.standard_normal(sd_np[k].shape)).astype(np.float32)
+    sd = R.to_torch(sd_np)
+    cfg = WhisperConfig(vocab_size=dims["n_vocab"], num_mel_bins=80, encoder_layers=4, encoder_attention_heads=6,
+                        decoder_layers=4, decoder_attention_heads=6, decoder_ffn_dim=1536, encoder_ffn_dim=1536,
+                        d_model=384, max_source_positions=1500, max_target_positions=448,
+                        activation_function="gelu", dropout=0.0, attention_dropout=0.0, activation_dropout=0.0,
+                        scale_embedding=False, pad_token_id=0, bos_token_id=1, eos_token_id=2,
+                        decoder_start_token_id=3)
+    m = WhisperModel(cfg).eval()
+    hf = W.openai_to_hf_state_dict(sd_np)
+    m.load_state_dict({k: torch.from_numpy(hf["model." + k]) for k in m.state_dict()})
+    mel = torch.from_numpy(np.random.default_rng(1).standard_normal((1, 80, 3000)).astype(np.float32) * 0.5)
+    toks = torch.tensor([[50257, 50362, 100, 2000, 7]])
+    with torch.no_grad():
+        out = m(input_features=mel, decoder_input_ids=toks)
+    xa = R.encode(sd, dims, mel)
+    assert R.rel_l2(xa.numpy(), out.encoder_last_hidden_state.numpy()) < 1e-5
+    lg = R.decode_logits(sd, dims, toks.numpy(), xa).numpy()
+    lg_hf = (out.last_hidden_state @ torch.from_numpy(hf["model.decoder.embed_tokens.weight"]).T).numpy()
+    assert R.rel_l2(lg, lg_hf) < 1e-5
+
+
+def test_checkpoint_converters(tmp_path):
+    """SURVEY 8f rank 2 (the step before Whisper.init; the reference's equivalent is whisper_to_cml.py:6-8): an
+    openai-whisper style `.pt` ({"dims", "model_state_dict"} in fp16, as the published checkpoints are) and an HF
+    `model.safetensors` (transformers key names, tied `proj_out`) both convert to the flat file with every tensor
+    intact."""
+    from safetensors.numpy import save_file
+    dims = dict(R.TINY_DIMS)
+    sd = _sd(9)
+    half = {k: torch.from_numpy(v).half() for k, v in sd.items()}
+    want = {k: v.float().numpy() for k, v in half.items()}
+    pt = os.path.join(tmp_path, "tiny.pt")
+    torch.save({"dims": dict(dims), "model_state_dict": half}, pt)
+    out1 = os.path.join(tmp_path, "from_pt.wm")
+    assert W.convert_openai_pt(pt, out1) == dims
+    d1, s1 = W.load_flat(out1)
+    assert d1 == dims and set(s1) == set(sd) and all(np.array_equal(s1[k], want[k]) for k in sd)
+    hf = {k: np.ascontiguousarray(v.astype(np.float16)) for k, v in W.openai_to_hf_state_dict(sd).items()}
+    hf["proj_out.weight"] = hf["model.decoder.embed_tokens.weight"].copy()        # tied output head: ignored by the converter
+    st = os.path.join(tmp_path, "model.safetensors")
+    save_file(hf, st)
+    out2 = os.path.join(tmp_path, "from_hf.wm")
+    W.convert_hf_safetensors(st, dims, out2)
+    d2, s2 = W.load_flat(out2)
+    assert d2 == dims and set(s2) == set(sd) and all(np.array_equal(s2[k], want[k]) for k in sd)

@@ -160,3 +160,38 @@ def test_run_grouped_surfaces_worker_errors():
         assert False
     except RuntimeError:
         pass
+
+
+# ---------------------------------------------------------------- wm_multi: the same split behind the C ABI (host-only parts)
+def test_c_abi_partition_and_gather_packing_match_the_python_path():
+    """wm_multi (csrc/multi.cpp) is the dlopen-only host's road to all 8 GPUs; its block partition and its fixed-stride
+    all-gather payload must be exactly what bench.py's torch.distributed path uses (sharding.partition / gather_tokens)."""
+    import ctypes
+    import openai_whisper_coreml_amd as pkg
+    lib = pkg.load_library()
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lo, hi = ctypes.c_int(), ctypes.c_int()
+    for n in (0, 1, 7, 8, 15, 120, 121):
+        for w in (1, 2, 3, 8):
+            for r in range(w):
+                assert lib.wm_multi_partition(n, w, r, ctypes.byref(lo), ctypes.byref(hi)) == 0
+                assert (lo.value, hi.value) == S.partition(n, w, r), (n, w, r)
+    assert lib.wm_multi_partition(5, 2, 2, ctypes.byref(lo), ctypes.byref(hi)) != 0          # rank out of range
+    # pack each rank's block, concatenate (= what ncclAllGather leaves on every rank), unpack: chunk order restored
+    n_chunks, world, max_new = 13, 4, 6
+    per = -(-n_chunks // world)
+    toks = np.array([[1000 * i + j for j in range(max_new)] for i in range(n_chunks)], np.int32)
+    lens = np.array([(i % max_new) + 1 for i in range(n_chunks)], np.int32)
+    gathered = np.zeros((world, per, 1 + max_new), np.int32)
+    for r in range(world):
+        a, b = S.partition(n_chunks, world, r)
+        t, l = np.ascontiguousarray(toks[a:b]), np.ascontiguousarray(lens[a:b])
+        pay = np.full((per, 1 + max_new), -7, np.int32)
+        assert lib.wm_multi_pack_tokens(P(t) if b > a else None, P(l) if b > a else None, b - a, per, max_new, P(pay)) == 0
+        assert np.array_equal(pay[:b - a, 0], l) and np.array_equal(pay[:b - a, 1:], t) and not pay[b - a:].any()
+        gathered[r] = pay
+    out_t = np.zeros((n_chunks, max_new), np.int32)
+    out_l = np.zeros(n_chunks, np.int32)
+    assert lib.wm_multi_unpack_tokens(P(gathered), world, per, max_new, n_chunks, P(out_t), P(out_l)) == 0
+    assert np.array_equal(out_t, toks) and np.array_equal(out_l, lens)
+    assert lib.wm_multi_unpack_tokens(P(gathered), world, per, max_new, world * per + 1, P(out_t), P(out_l)) != 0

@@ -11,7 +11,7 @@ import numpy as np
 
 
 def short(n):
-    m = re.search(r"(dec_gemv_kernelILi\d+ELi\dELb\d|dec_rows_attn_kernelILi\dELi\dELb\d|gemm256_bf16_kernelILi\d|"
+    m = re.search(r"(dec_gemv_kernelILi\d+ELi\dELi\dELi\dELb\d|dec_rows_attn_kernelILi\dELi\dELb\d|gemm256_bf16_kernelILi\d|"
                   r"gemm_bf16_kernelILi\d|enc_attn_kernel|layernorm_kernel|argmax_embed_kernel|dec_\w+?_kernel|logmel_stage\d)", n)
     return m.group(1) if m else n[:40]
 
