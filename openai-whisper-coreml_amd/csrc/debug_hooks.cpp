@@ -156,7 +156,13 @@ extern "C" int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, co
     for (size_t r = 0; r < (size_t)N; ++r)
         for (size_t k = 0; k < (size_t)K; ++k) wp[wm_tiled_offset(r, k, (size_t)K)] = W[r * K + k];
     to_bf16(wp.data(), w16, wp.size());
-    to_bf16(x, x16, (size_t)B * K);
+    {   // activations in the fragment-tiled order the decoder keeps them in (rows padded to 16)
+        const int Bpad = ((B + 15) / 16) * 16;
+        std::vector<float> xp((size_t)Bpad * K, 0.f);
+        for (size_t b = 0; b < (size_t)B; ++b)
+            for (size_t k = 0; k < (size_t)K; ++k) xp[wm_tiled_offset(b, k, (size_t)K)] = x[b * K + k];
+        to_bf16(xp.data(), x16, xp.size());
+    }
     void *dx16, *dg = nullptr, *db = nullptr, *dW, *dWf = nullptr, *dc1 = nullptr, *dc2 = nullptr, *dbias = nullptr, *dout;
     hipStream_t s = ctx->stream;
     WM_TRY(up(&dx16, x16.data(), x16.size() * 2, s));
@@ -218,7 +224,7 @@ extern "C" int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, 
     WM_TRY(up(&dv, v16.data(), v16.size() * 2, s));
     WM_TRY(up(&dp, nullptr, (size_t)B * H * WM_MAXSPLIT * 66 * 4, s));
     void *datt;
-    WM_TRY(up(&datt, nullptr, (size_t)B * H * 64 * 2, s));
+    WM_TRY(up(&datt, nullptr, ((size_t)B + 15) / 16 * 16 * H * 64 * 2, s));
     // nsplit == 0 selects the decoder's self-attention kernel (one 4-wave workgroup per pair), nsplit == -1 the
     // cross-attention launch path (8-wave block-streaming kernel, capped grid)
     int rc = nsplit == 0 ? wm_dec_self_attention(ctx, (const float *)dq, (const bf16_t *)dk, (const bf16_t *)dv, B, H, T,
@@ -226,10 +232,13 @@ extern "C" int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, 
                          : wm_dec_attention(ctx, (const float *)dq, (const bf16_t *)dk, (const bf16_t *)dv, B, H, T, n_keys,
                                             nullptr, nsplit < 0 ? 1 : nsplit, (float *)dp, (bf16_t *)datt, nsplit < 0);
     if (rc == WM_OK) {
-        std::vector<bf16_t> o16((size_t)B * H * 64);
+        const size_t Bpad = ((size_t)B + 15) / 16 * 16, dd = (size_t)H * 64;
+        std::vector<bf16_t> o16(Bpad * dd), lin((size_t)B * dd);
         WM_HIP(hipMemcpyAsync(o16.data(), datt, o16.size() * 2, hipMemcpyDeviceToHost, s));
         WM_HIP(hipStreamSynchronize(s));
-        from_bf16(o16, out);
+        for (size_t b = 0; b < (size_t)B; ++b)   // head outputs are stored in the out-projection's tiled A-operand order
+            for (size_t k = 0; k < dd; ++k) lin[b * dd + k] = o16[wm_tiled_offset(b, k, dd)];
+        from_bf16(lin, out);
     }
     (void)hipFree(datt);
     (void)hipFree(dq); (void)hipFree(dk); (void)hipFree(dv); (void)hipFree(dp);
@@ -306,7 +315,7 @@ extern "C" int wmdbg_bench_dec_attention(wm_ctx *ctx, int B, int H, int T, int n
     WM_TRY(up(&dv, nullptr, slice * n_slices * 2, s));
     WM_TRY(up(&dq, nullptr, (size_t)B * H * 64 * 4, s));
     WM_TRY(up(&dp, nullptr, (size_t)B * H * WM_MAXSPLIT * 66 * 4, s));
-    WM_TRY(up(&datt, nullptr, (size_t)B * H * 64 * 2, s));
+    WM_TRY(up(&datt, nullptr, ((size_t)B + 15) / 16 * 16 * H * 64 * 2, s));
     hipEvent_t e0, e1;
     WM_HIP(hipEventCreate(&e0));
     WM_HIP(hipEventCreate(&e1));

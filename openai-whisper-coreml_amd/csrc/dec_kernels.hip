@@ -258,7 +258,7 @@ __device__ __forceinline__ void gemv_unit_epilogue(const DecGemvDev &p, const Ge
             if (bvalid && nvalid) {
                 xn = o.xold[r] + v;
                 p.out_f32[(long)b * p.ldo + n] = xn;
-                if (p.out_bf16) p.out_bf16[(long)b * p.ldo + n] = f2bf(xn);
+                if (p.out_bf16) p.out_bf16[wm_tiled_offset((size_t)b, (size_t)n, (size_t)p.ldo)] = f2bf(xn);
             }
             float s1 = xn, s2 = xn * xn;
 #pragma unroll
@@ -283,7 +283,7 @@ __device__ __forceinline__ void gemv_unit_epilogue(const DecGemvDev &p, const Ge
         } else if (EPI == DE_Q) {
             p.out_f32[(long)b * p.ldo + n] = v;
         } else if (EPI == DE_GELU) {
-            p.out_bf16[(long)b * p.ldo + n] = f2bf(gelu_erf(v));
+            p.out_bf16[wm_tiled_offset((size_t)b, (size_t)n, (size_t)p.ldo)] = f2bf(gelu_erf(v));
         }
     }
 }
@@ -309,7 +309,7 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1) ? 512 : 1024) vo
     float *red = (float *)smem;
     float *st = red + NW * NU * 256 + (threadIdx.x >> 6) * 32;  // wave-private
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nrow = lane & 15, kq = lane >> 4;
+    const int nrow = lane & 15;
     const int tile0 = tg * TN;
     const int bb = grp * NBLK * 16;  // first batch row of this workgroup (< B by construction of the grid)
 
@@ -323,15 +323,19 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1) ? 512 : 1024) vo
 #pragma unroll
         for (int u = 0; u < SPW; ++u) wf[t][u] = __builtin_nontemporal_load((const u32x4 *)(wp + u * 512));
     }
-    // ... the activation fragments of its batch blocks ...
-    const int kbase = wave * SPW * 32 + kq * 8;
+    // ... the activation fragments of its batch blocks: the activations are stored fragment-tiled exactly like the
+    // weights (block of 16 rows x k-step = one contiguous KiB in MFMA A-operand order, written that way by their
+    // producers), so this is ONE perfectly coalesced dwordx4 per lane per step too -- a row-major [B][K] buffer costs
+    // 16 half-used cache lines per wave-load and twice the L2 -> CU traffic.  Rows past B inside the last block hold
+    // stale data: an MFMA output row depends on its own A row only, and those rows are never stored ...
     u32x4 af[NBLK][SPW];
 #pragma unroll
     for (int j = 0; j < NBLK; ++j) {
-        const int rb = bb + j * 16 + nrow;
-        const bf16_t *ap = p.a + (long)(rb < p.B ? rb : p.B - 1) * p.K + kbase;  // clamped row
+        const int blk = (bb >> 4) + j;
+        const int blkc = blk * 16 < p.B ? blk : (bb >> 4);  // a missing second block re-reads the first (never used)
+        const bf16_t *ap = p.a + (((long)blkc * (p.K >> 5) + (long)wave * SPW) * 64 + lane) * 8;
 #pragma unroll
-        for (int u = 0; u < SPW; ++u) af[j][u] = *(const u32x4 *)(ap + u * 32);
+        for (int u = 0; u < SPW; ++u) af[j][u] = *(const u32x4 *)(ap + u * 512);
     }
     // ... and the epilogue operands of the (tile, block) unit this wave will finish: unit u = j * TN + t -> wave u % NW
     int pos = 0;
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int *__restrict__ 
     for (int j = threadIdx.x; j < d; j += 256) {
         const float v = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)pos * d + j];
         x[(long)b * d + j] = v;
-        xb[(long)b * d + j] = f2bf(v);
+        xb[wm_tiled_offset((size_t)b, (size_t)j, (size_t)d)] = f2bf(v);
         s1 += v;
         s2 += v * v;
     }
@@ -615,7 +619,8 @@ __global__ __launch_bounds__(NS * 64) void dec_rows_attn_kernel(const float *__r
             }
         }
         __syncthreads();
-        if (tid < 64) att[(long)b * d + h * 64 + tid] = f2bf(attn_merge<NS>(wm_, wl_, &wo_[0][0], 64, tid));
+        if (tid < 64)  // head outputs feed the out-projection GEMV: stored in its fragment-tiled A-operand order
+            att[wm_tiled_offset((size_t)b, (size_t)(h * 64 + tid), (size_t)d)] = f2bf(attn_merge<NS>(wm_, wl_, &wo_[0][0], 64, tid));
     }
 }
 
@@ -632,7 +637,7 @@ __global__ __launch_bounds__(64) void dec_attn_combine_kernel(const float *__res
         wl_[e] = pp[e * 66 + 1];
     }
     __syncthreads();
-    att[(long)b * d + h * 64 + e] = f2bf(attn_merge<NS>(wm_, wl_, pp + 2, 66, e));
+    att[wm_tiled_offset((size_t)b, (size_t)(h * 64 + e), (size_t)d)] = f2bf(attn_merge<NS>(wm_, wl_, pp + 2, 66, e));
 }
 
 // ------------------------------------------------------------------ arg-max -> next token
@@ -744,7 +749,7 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
             for (int j = lane; j < d; j += 64) {
                 const float v = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)(pos + 1) * d + j];
                 x[(long)b * d + j] = v;
-                xb[(long)b * d + j] = f2bf(v);
+                xb[wm_tiled_offset((size_t)b, (size_t)j, (size_t)d)] = f2bf(v);
                 s1 += v;
                 s2 += v * v;
             }

@@ -114,12 +114,12 @@ struct WmModel {
     bf16_t *skv = nullptr;    // [L][2][B][H][n_text_ctx][64] self-attention K/V cache
     // decode-step buffers
     float *dx = nullptr;        // [B][d]    decoder residual stream (f32)
-    bf16_t *dxb = nullptr;      // [B][d]    its bf16 copy: the A operand of the LayerNorm-folded GEMVs
+    bf16_t *dxb = nullptr;      // [B][d]    its bf16 copy: the A operand of the LayerNorm-folded GEMVs (WL_TILED order)
     float *dq = nullptr;        // [16][d]   query (self or cross)
     float *dpart = nullptr;     // [16][H][WM_MAXSPLIT][66] attention partials (m, l, o[64])
     float *dstats = nullptr;    // [B/16][d/16][16][2] LayerNorm partial statistics of the residual stream
-    bf16_t *datt = nullptr;     // [16][d]   attention head outputs (bf16 A operand of the out-projection)
-    bf16_t *dhid = nullptr;     // [16][4d]
+    bf16_t *datt = nullptr;     // [B][d]    attention head outputs (bf16 A operand of the out-projection; WL_TILED order)
+    bf16_t *dhid = nullptr;     // [B][4d]   GELU(fc1) (A operand of fc2; WL_TILED order)
     float *dlogits = nullptr;   // [B][vpad]
     unsigned long long *dargmax = nullptr;  // [16][vpad/16] per-tile packed (value, ~index) maxima
     int *dresult = nullptr;     // [16] arg-max result relative to arg_first
@@ -220,13 +220,13 @@ struct DecGemvArgs {
     const bf16_t *W;    // [N (padded to 16)][K] in WL_TILED order; LayerNorm mode: the gamma-folded copy
     const float *c1;    // LayerNorm mode (non-null): column sums of the folded weights, see DecLayerW
     const float *c2;    // [N] bias (LayerNorm mode: + beta fold) or null
-    const bf16_t *a;    // [B][K] bf16 activations
+    const bf16_t *a;    // [B padded to 16][K] bf16 activations in WL_TILED order (wm_tiled_offset(b, k, K))
     const float *stats_in; // LayerNorm mode: [B/16][K/16][16][2] partial (sum, sum of squares) per row of the f32 residual,
     int stats_parts;       //                 from the producer of the residual (always K/16 parts; unused ones are zero)
     float *stats_out;      // DE_RESID: [B/16][N/16][16][2] partials of the updated residual (may be null)
     // outputs
     float *out_f32;        // DE_QKV: q [B][N/3]; DE_Q: [B][ldo]; DE_RESID: residual [B][ldo] (+=); DE_LOGITS: [B][ldo] or null
-    bf16_t *out_bf16;      // DE_GELU: [B][ldo]; DE_RESID: bf16 copy of the updated residual (may be null)
+    bf16_t *out_bf16;      // DE_GELU: [B][ldo]; DE_RESID: bf16 copy of the updated residual (may be null); WL_TILED order
     bf16_t *kcache, *vcache;  // DE_QKV: this layer's [B][H][T][64]
     const int *pos_ptr;       // device-side decode position (DE_QKV appends at *pos_ptr)
     int n_ctx, n_head;
@@ -251,7 +251,7 @@ int wm_ln_fold(wm_ctx *ctx, const bf16_t *W, const float *g, const float *beta, 
 // x[b] = token_embedding[seq[*pos_ptr][b]] + positional_embedding[*pos_ptr]
 int wm_dec_embed(wm_ctx *ctx, const int *seq, const int *pos_ptr, int B, const bf16_t *emb, const float *pemb,
                  int d, float *x, bf16_t *xb, float *stats_out);
-// Single-query attention over a K/V cache [B][H][T_stride][64] -> bf16 head outputs att[B][H*64].
+// Single-query attention over a K/V cache [B][H][T_stride][64] -> bf16 head outputs att[B][H*64] in WL_TILED order.
 // Keys 0 .. n-1 with n = *pos_ptr + 1 when pos_ptr != null, else n_keys.
 int wm_dec_attn_splits(int B, int H);
 int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
