@@ -22,7 +22,7 @@ HOST_BIN = os.path.join(HERE, "host", "lid_main")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fvisibility=hidden",   # only the WM_API functions of include/*.h are exported
-         "-I", os.path.join(ROOT, "include")]
+         "-I", os.path.join(ROOT, "include")] + os.environ.get("WM_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def sources():

@@ -512,7 +512,7 @@ __global__ __launch_bounds__(NS * 64) void dec_rows_attn_kernel(const float *__r
                                                                 const int *__restrict__ pos_ptr,
                                                                 bf16_t *__restrict__ att, float *__restrict__ part,
                                                                 int nsplit, int n_bh, int n_wg,
-                                                                const char *pf_ptr, long pf_tile_bytes) {
+                                                                const char *pf_ptr, long pf_tile_bytes, int flat_wpw) {
     if ((int)blockIdx.x >= n_wg) {  // L2 warm-up workgroup for the next GEMV's weights
         l2_warm_tile(pf_ptr, pf_tile_bytes, (int)blockIdx.x - n_wg, blockDim.x);
         return;
@@ -523,10 +523,21 @@ __global__ __launch_bounds__(NS * 64) void dec_rows_attn_kernel(const float *__r
     const int rg = lane >> 3, e8 = lane & 7;
     const int n_keys = pos_ptr ? (*pos_ptr + 1) : n_keys_const;
     const int last = n_keys - 1;
-    const int stream = (int)blockIdx.y * (NS / nsplit) + wave;  // blockDim.x == (NS / nsplit) * 64
+    // FLAT launch (few pairs): the n_bh * NS (pair, stream) units are dealt to the waves of the grid one to one,
+    // flat_wpw waves per workgroup, so that every CU streams an equal share whatever the pair count (B = 8 x 20 heads:
+    // 1280 units = 256 workgroups of 5 waves); the waves of a workgroup are independent (partials to `part`, no barrier).
+    int stream = (int)blockIdx.y * (NS / nsplit) + wave;  // blockDim.x == (NS / nsplit) * 64
+    int bh0 = blockIdx.x, bh_step = n_wg;
+    if (flat_wpw > 0) {
+        const int unit = (int)blockIdx.x * flat_wpw + wave;
+        if (unit >= n_bh * NS) return;  // wave-uniform
+        bh0 = unit / NS;
+        stream = unit % NS;
+        bh_step = n_bh;  // one pair per wave
+    }
     // n_wg <= n_bh workgroups (per split) walk the (sequence, head) pairs
-    for (int bh = blockIdx.x; bh < n_bh; bh += n_wg) {
-        if (bh != (int)blockIdx.x) __syncthreads();  // the previous pair's merge has been read
+    for (int bh = bh0; bh < n_bh; bh += bh_step) {
+        if (flat_wpw == 0 && bh != (int)blockIdx.x) __syncthreads();  // the previous pair's merge has been read
         const int b = bh / H, h = bh % H;
         const bf16_t *kb = kc + (long)bh * T_stride * 64 + e8 * 8;
         const bf16_t *vb = vc + (long)bh * T_stride * 64 + e8 * 8;
@@ -972,8 +983,13 @@ int wm_dec_embed(wm_ctx *ctx, const int *seq, const int *pos_ptr, int B, const b
 // Workgroups per (sequence, head) pair of the cross-attention: 1 when the pairs alone fill the chip, else the stream
 // set of a pair is dealt to 2, 4 or 8 workgroups.  A launch-shape choice: the arithmetic does not depend on it.
 int wm_dec_attn_splits(int B, int H) {
+    static const int env_thr = getenv("WM_XATTN_SPLIT_BELOW") ? atoi(getenv("WM_XATTN_SPLIT_BELOW")) : -1;
     const int bh = B * H;
-    if (bh >= 96) return 1;
+    // few pairs: the (pair, stream) units are dealt flat over the chip and merged by a combine launch.  (Measured at
+    // B = 8 x 20 heads = 160 pairs: flat 11.5 + combine 3.0 us vs 12.2 us for one 8-wave workgroup per pair -- the kernel
+    // is bound by bytes in flight per CU, not by idle CUs -- so the split starts below 96 pairs only.)
+    const int thr = env_thr >= 0 ? env_thr : 96;
+    if (bh >= thr) return 1;
     int ns = 2;
     while (ns < 8 && bh * ns < 192) ns *= 2;
     return ns;
@@ -1006,9 +1022,21 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
             tile_bytes = 16L * pf_k * 2;
             gx += pf_rows / 16;
         }
-        dim3 grid(gx, nsplit);
-        dec_rows_attn_kernel<8, 4, true><<<grid, (8 / nsplit) * 64, 0, ctx->stream>>>(
-            q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, nsplit, B * H, n_wg, (const char *)pf_ptr, tile_bytes);
+        static const bool no_flat = getenv("WM_XATTN_NO_FLAT") != nullptr;
+        if (nsplit > 1 && !no_flat) {
+            // few pairs: deal the (pair, stream) units evenly over ~256 workgroups (see the kernel)
+            const int units = B * H * 8;
+            int wpw = (units + 255) / 256;
+            wpw = wpw < 1 ? 1 : (wpw > 8 ? 8 : wpw);
+            const int g = (units + wpw - 1) / wpw;
+            dec_rows_attn_kernel<8, 4, true><<<g, wpw * 64, 0, ctx->stream>>>(
+                q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, 8, B * H, g, nullptr, 0, wpw);
+        } else {
+            dim3 grid(gx, nsplit);
+            dec_rows_attn_kernel<8, 4, true><<<grid, (8 / nsplit) * 64, 0, ctx->stream>>>(
+                q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, nsplit, B * H, n_wg, (const char *)pf_ptr,
+                tile_bytes, 0);
+        }
         WM_HIP(hipGetLastError());
     }
     if (nsplit > 1) {
@@ -1033,7 +1061,7 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
     }
     // a pair is 15-57 KB of cache (<= 448 rows, ~115 on average over a 224-token decode): ONE 4-wave workgroup
     dec_rows_attn_kernel<4, 4, false><<<gx, 256, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att,
-                                                                  nullptr, 1, B * H, B * H, (const char *)pf_ptr, tile_bytes);
+                                                                  nullptr, 1, B * H, B * H, (const char *)pf_ptr, tile_bytes, 0);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

@@ -228,4 +228,20 @@ void oracle_logmel_batch_f32(const float *pcm, int n_chunks, double *out) {
     free(buf);
 }
 
+/* The same, chunk-parallel over all host cores (OpenMP): NOT how the reference runs (its crate is single-threaded), but
+ * the fairest CPU number for a batch of independent chunks (SURVEY.md 8d asks for both; bench.py labels them). */
+void oracle_logmel_batch_f32_omp(const float *pcm, int n_chunks, double *out) {
+#pragma omp parallel
+    {
+        double *buf = (double *)malloc(sizeof(double) * N_PADDED);
+#pragma omp for schedule(dynamic, 1)
+        for (int c = 0; c < n_chunks; ++c) {
+            memset(buf, 0, sizeof(double) * N_PADDED);
+            for (int i = 0; i < N_SAMPLES; ++i) buf[200 + i] = (double)pcm[(size_t)c * N_SAMPLES + i];
+            generate_spectrogram_impl(buf, out + (size_t)c * 80 * N_FRAMES);
+        }
+        free(buf);
+    }
+}
+
 const float *oracle_mel80(void) { return MEL80; }
