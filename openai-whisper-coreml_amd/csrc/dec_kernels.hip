@@ -891,11 +891,21 @@ static void pick_shape(int epi, bool ln, int spw, int B, int n_tiles, int *tn, i
     *nblk = env_nb == 1 ? 1 : 2;
     const bool wide = ln && (epi == DE_QKV || epi == DE_GELU || epi == DE_LOGITS) && *nblk == 2 && spw <= 6;
     if (!wide) return;
+    // Tile-group width by RESIDENCY ROUNDS: an 8-wave workgroup of the (1, 2) shape needs <= 128 VGPRs and sits two per
+    // CU, the wide shapes (136-190 VGPRs) one per CU; a grid that needs a second round of the chip costs a whole kernel
+    // time (measured: fc1 at 56 rows as 320 one-per-CU workgroups = two rounds), so: fewest rounds first, then the
+    // narrowest group that still leaves >= 192 workgroups, else the widest.
     const int g = (blocks + 1) / 2;
-    int t = 1;
-    while (t < 4 && (n_tiles / (2 * t)) * g >= 256) t *= 2;  // keep >= 256 workgroups
-    if (env_tn == 1 || env_tn == 2 || env_tn == 4) t = env_tn;
-    *tn = t;
+    int best = 1, best_rounds = 1 << 30, best_wgs = 0;
+    for (int t = 1; t <= 4; t *= 2) {
+        const int wgs = ((n_tiles + t - 1) / t) * g;
+        const int cap = 256 * (t == 1 ? 2 : 1);
+        const int rounds = (wgs + cap - 1) / cap;
+        const bool better = rounds < best_rounds || (rounds == best_rounds && best_wgs >= 192 && wgs >= 192);
+        if (better) { best = t; best_rounds = rounds; best_wgs = wgs; }
+    }
+    if (env_tn == 1 || env_tn == 2 || env_tn == 4) best = env_tn;
+    *tn = best;
 }
 
 int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
