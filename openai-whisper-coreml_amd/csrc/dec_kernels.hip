@@ -61,6 +61,14 @@ struct DecGemvDev {
     int stats_parts;
     long stats_stride;      // floats between the statistics of consecutive 16-row batch blocks
     float *stats_out;       // DE_RESID: this launch's per-tile partials of the UPDATED residual
+    // The bf16 copy of the residual is stored MEAN-CENTRED: xb = bf16(x - off_b), off_b = the row's LayerNorm mean as of
+    // the previous LayerNorm (mean_in).  bf16 rounding then scales with |x - mean| (as it did when the normalised row was
+    // rounded), not with |x|: a common-mode offset of the stream -- which LayerNorm removes -- would otherwise cost
+    // 2^-9 |offset| per element (measured: offset 1.0 at std 0.2 -> logits rel-L2 4.6e-2; 10.0 -> 0.43).  The LayerNorm-
+    // folded GEMV reads the same offset, uses (mean - off) in the fold and leaves the new mean in mean_out (the other
+    // buffer of a ping-pong pair, so no workgroup of the launch can see it).  Null: offset 0 / nothing written.
+    const float *mean_in;
+    float *mean_out;
     float *out_f32;
     bf16_t *out_bf16;
     bf16_t *kcache, *vcache;
@@ -120,6 +128,8 @@ template <int EPI, bool LN>
 struct GemvUnitOps {
     float c1v, c2v;
     float xold[4];
+    float off4[4];   // DE_RESID: mean-centring offsets of the lane's four rows
+    float offrow;    // LayerNorm modes: offset of row (lane & 15) of the block
     int4 trng[4];
     float2 sv[LN ? 20 : 1];  // statistics parts per lane group: d/16 <= 80 parts
 };
@@ -136,15 +146,20 @@ __device__ __forceinline__ void gemv_unit_load(const DecGemvDev &p, GemvUnitOps<
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         o.xold[r] = 0.f;
+        o.off4[r] = 0.f;
         o.trng[r] = make_int4(0, 0, 0, 0);
     }
+    o.offrow = 0.f;
     if (EPI == DE_RESID) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int bl = kq * 4 + r;
-            o.xold[r] = p.out_f32[(long)(b0 + (bl < nb ? bl : nb - 1)) * p.ldo + nc];
+            const int bc = b0 + (bl < nb ? bl : nb - 1);
+            o.xold[r] = p.out_f32[(long)bc * p.ldo + nc];
+            if (p.mean_in) o.off4[r] = p.mean_in[bc];
         }
     }
+    if (LN && p.mean_in) o.offrow = p.mean_in[b0 + (nrow < nb ? nrow : nb - 1)];
     if (EPI == DE_LOGITS && p.ts.rng) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -169,7 +184,8 @@ __device__ __forceinline__ void gemv_unit_load(const DecGemvDev &p, GemvUnitOps<
 // the four rows its accumulator registers hold.  The partial sums were written in a FIXED slab order by the producer
 // of the residual, so this sum is deterministic and needs no atomics.
 template <int EPI, bool LN>
-__device__ __forceinline__ void gemv_unit_stats(const DecGemvDev &p, const GemvUnitOps<EPI, LN> &o, float *st, int lane) {
+__device__ __forceinline__ void gemv_unit_stats(const DecGemvDev &p, const GemvUnitOps<EPI, LN> &o, float *st, int lane,
+                                                int tile, int b0) {
     if (!LN) return;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -183,7 +199,11 @@ __device__ __forceinline__ void gemv_unit_stats(const DecGemvDev &p, const GemvU
     float var = s2 / (float)p.K - mean * mean;
     var = var > 0.f ? var : 0.f;
     const float rstd = rsqrtf(var + 1e-5f);
-    if (lane < 16) *(float2 *)(st + lane * 2) = make_float2(rstd, -mean * rstd);
+    if (lane < 16) {
+        // the activations are stored as bf16(x - off): the fold needs (mean - off) where it had mean
+        *(float2 *)(st + lane * 2) = make_float2(rstd, -(mean - o.offrow) * rstd);
+        if (tile == 0 && p.mean_out && b0 + lane < p.B) p.mean_out[b0 + lane] = mean;  // one writer per row
+    }
 }
 
 // epilogue of one (tile, block) unit by one wave: D col n = lane & 15, rows b = b0 + kq*4 + r
@@ -258,7 +278,7 @@ __device__ __forceinline__ void gemv_unit_epilogue(const DecGemvDev &p, const Ge
             if (bvalid && nvalid) {
                 xn = o.xold[r] + v;
                 p.out_f32[(long)b * p.ldo + n] = xn;
-                if (p.out_bf16) p.out_bf16[wm_tiled_offset((size_t)b, (size_t)n, (size_t)p.ldo)] = f2bf(xn);
+                if (p.out_bf16) p.out_bf16[wm_tiled_offset((size_t)b, (size_t)n, (size_t)p.ldo)] = f2bf(xn - o.off4[r]);
             }
             float s1 = xn, s2 = xn * xn;
 #pragma unroll
@@ -378,7 +398,7 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1) ? 512 : 1024) vo
 #pragma unroll
             for (int t = 0; t < TN; ++t) *(f32x4 *)(red + ((wave * NU + j * TN + t) * 64 + lane) * 4) = acc[j][t];
     }
-    if (has_unit) gemv_unit_stats<EPI, LN>(p, ops, st, lane);
+    if (has_unit) gemv_unit_stats<EPI, LN>(p, ops, st, lane, utile, ub0);
     __syncthreads();
     // ---- 4. fused epilogues: unit u on wave u % NW (first unit's operands are already here)
     for (int u = wave; u < NU; u += NW) {  // wave-uniform
@@ -387,7 +407,7 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1) ? 512 : 1024) vo
         if (tile >= p.n_tiles || b0 >= p.B) continue;
         if (u != wave) {  // more units than waves (small models): operands fetched late
             gemv_unit_load<EPI, LN>(p, ops, tile, b0, lane);
-            gemv_unit_stats<EPI, LN>(p, ops, st, lane);
+            gemv_unit_stats<EPI, LN>(p, ops, st, lane, tile, b0);
             if (EPI == DE_LOGITS && p.mask) {
                 const int n = tile * 16 + nrow;
                 const int nc = n < p.N ? n : p.N - 1;
@@ -440,7 +460,7 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int *__restrict__ 
                                                         int B, const bf16_t *__restrict__ emb,
                                                         const float *__restrict__ pemb, int d,
                                                         float *__restrict__ x, bf16_t *__restrict__ xb,
-                                                        float *__restrict__ stats_out) {
+                                                        float *__restrict__ stats_out, float *__restrict__ mean_buf) {
     __shared__ float r1[4], r2[4];
     const int b = blockIdx.x;
     const int pos = *pos_ptr;
@@ -449,7 +469,6 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int *__restrict__ 
     for (int j = threadIdx.x; j < d; j += 256) {
         const float v = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)pos * d + j];
         x[(long)b * d + j] = v;
-        xb[wm_tiled_offset((size_t)b, (size_t)j, (size_t)d)] = f2bf(v);
         s1 += v;
         s2 += v * v;
     }
@@ -463,7 +482,12 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int *__restrict__ 
         r2[threadIdx.x >> 6] = s2;
     }
     __syncthreads();
-    // LayerNorm partial statistics of this row: a single part (index 0)
+    {   // bf16 copy, mean-centred (see DecGemvDev::mean_in); the row mean is what the first LayerNorm will compute
+        const float mean = ((r1[0] + r1[1]) + (r1[2] + r1[3])) / (float)d;
+        for (int j = threadIdx.x; j < d; j += 256)
+            xb[wm_tiled_offset((size_t)b, (size_t)j, (size_t)d)] = f2bf(x[(long)b * d + j] - mean);
+        if (threadIdx.x == 0 && mean_buf) mean_buf[b] = mean;
+    }
     // the whole row is ONE part (index 0); the consumers always sum d/16 parts, so the others are zeroed
     if (stats_out) {
         float *blk = stats_out + (long)(b >> 4) * (2 * d) + (b & 15) * 2;  // block of 16 rows: [d/16 parts][16][2]
@@ -666,7 +690,8 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
                                                              const float *__restrict__ pemb, int d, int n_ctx,
                                                              float *__restrict__ x, bf16_t *__restrict__ xb,
                                                              float *__restrict__ stats_out, WmTsDev ts,
-                                                             int *__restrict__ arrive, int fallback_tok) {
+                                                             int *__restrict__ arrive, int fallback_tok,
+                                                             float *__restrict__ mean_buf) {
     __shared__ int tok_s[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pos = pos_ptr ? *pos_ptr : 0;
@@ -760,7 +785,6 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
             for (int j = lane; j < d; j += 64) {
                 const float v = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)(pos + 1) * d + j];
                 x[(long)b * d + j] = v;
-                xb[wm_tiled_offset((size_t)b, (size_t)j, (size_t)d)] = f2bf(v);
                 s1 += v;
                 s2 += v * v;
             }
@@ -768,6 +792,12 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
             for (int o = 32; o > 0; o >>= 1) {
                 s1 += __shfl_xor(s1, o);
                 s2 += __shfl_xor(s2, o);
+            }
+            {   // bf16 copy, mean-centred (see DecGemvDev::mean_in); each lane re-reads the elements it just wrote
+                const float mean = s1 / (float)d;
+                for (int j = lane; j < d; j += 64)
+                    xb[wm_tiled_offset((size_t)b, (size_t)j, (size_t)d)] = f2bf(x[(long)b * d + j] - mean);
+                if (lane == 0 && mean_buf) mean_buf[b] = mean;
             }
             if (stats_out) {  // one part (index 0) carries the row; the other d/16 - 1 parts the consumers sum are zero
                 float *blk = stats_out + (long)(b >> 4) * (2 * d) + (b & 15) * 2;
@@ -923,6 +953,7 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     p.B = a.B; p.N = a.N; p.K = a.K;
     p.W = a.W; p.c1 = a.c1; p.c2 = a.c2; p.a = a.a;
     p.stats_in = a.stats_in; p.stats_parts = a.K / 16; p.stats_out = a.stats_out;
+    p.mean_in = a.mean_in; p.mean_out = a.mean_out;
     p.stats_stride = 2L * (a.epi == DE_RESID ? a.N : a.K);  // [parts <= d/16][16][2] floats per block of 16 rows
     p.out_f32 = a.out_f32; p.out_bf16 = a.out_bf16;
     p.kcache = a.kcache; p.vcache = a.vcache; p.pos_ptr = a.pos_ptr; p.n_ctx = a.n_ctx; p.n_head = a.n_head;
@@ -983,9 +1014,9 @@ int wm_ln_fold(wm_ctx *ctx, const bf16_t *W, const float *g, const float *beta, 
 }
 
 int wm_dec_embed(wm_ctx *ctx, const int *seq, const int *pos_ptr, int B, const bf16_t *emb, const float *pemb,
-                 int d, float *x, bf16_t *xb, float *stats_out) {
+                 int d, float *x, bf16_t *xb, float *stats_out, float *mean_buf) {
     WmProfScope ps(&ctx->prof, "dec_embed", ctx->stream);
-    dec_embed_kernel<<<B, 256, 0, ctx->stream>>>(seq, pos_ptr, B, emb, pemb, d, x, xb, stats_out);
+    dec_embed_kernel<<<B, 256, 0, ctx->stream>>>(seq, pos_ptr, B, emb, pemb, d, x, xb, stats_out, mean_buf);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }
@@ -1078,7 +1109,8 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
 
 int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
                     int n_prompt, int *result, int arg_first, const bf16_t *emb, const float *pemb, int d, int n_ctx,
-                    float *x, bf16_t *xb, float *stats_out, const WmTsDev *ts, int *arrive, int fallback_tok) {
+                    float *x, bf16_t *xb, float *stats_out, const WmTsDev *ts, int *arrive, int fallback_tok,
+                    float *mean_buf) {
     WmProfScope ps(&ctx->prof, "argmax_embed", ctx->stream);
     WmTsDev t;
     memset(&t, 0, sizeof(t));
@@ -1087,7 +1119,8 @@ int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles,
     WM_REQUIRE(grid == 1 || B <= 16 * grid, WM_ERR_INVALID, "argmax_embed: bad grid");
     WM_REQUIRE(arrive || B <= 16, WM_ERR_INVALID, "argmax_embed: more than 16 rows need the arrival counter");
     argmax_embed_kernel<<<grid, 1024, 0, ctx->stream>>>(tilemax, n_tiles, B, seq, pos_ptr, n_prompt, result, arg_first,
-                                                        emb, pemb, d, n_ctx, x, xb, stats_out, t, arrive, fallback_tok);
+                                                        emb, pemb, d, n_ctx, x, xb, stats_out, t, arrive, fallback_tok,
+                                                        mean_buf);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

@@ -47,6 +47,7 @@ static int alloc_decode_buffers(WmModel *m, hipStream_t s) {
     // decode-step buffers (batch <= WM_DEC_MAXB)
     WM_TRY(dalloc_t(m, &m->dx, (size_t)WM_DEC_MAXB * d, s));
     WM_TRY(dalloc_t(m, &m->dxb, (size_t)WM_DEC_MAXB * d, s));
+    WM_TRY(dalloc_t(m, &m->dmean, (size_t)2 * WM_DEC_MAXB, s));
     WM_TRY(dalloc_t(m, &m->dq, (size_t)WM_DEC_MAXB * d, s));
     WM_TRY(dalloc_t(m, &m->dpart, (size_t)WM_DEC_MAXB * D.n_text_head * WM_MAXSPLIT * 66, s));
     WM_TRY(dalloc_t(m, &m->datt, (size_t)WM_DEC_MAXB * d, s));
@@ -544,6 +545,10 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
     const int ns = wm_dec_attn_splits(B, H);
     static const int env_xns = getenv("WM_XATTN_SPLITS") ? atoi(getenv("WM_XATTN_SPLITS")) : 0;  // A/B probe
     const int xns = env_xns > 0 ? env_xns : ns;
+    // mean-centring offsets of the bf16 residual copy: the embedding wrote buffer 0; every LayerNorm-folded GEMV reads
+    // the current buffer and leaves the new means in the other one
+    int cur = 0;
+    auto mean_buf = [&](int i) { return m->dmean + (size_t)i * WM_DEC_MAXB; };
     for (int l = 0; l < D.n_text_layer; ++l) {
         const DecLayerW &L = m->dec[l];
         bf16_t *kc = m->skv + (size_t)(l * 2 + 0) * B * H * T * 64;
@@ -556,6 +561,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.epi = DE_QKV; a.B = B; a.N = 3 * d; a.K = d; a.W = L.wqkv_f; a.c1 = L.qkv_c1; a.c2 = L.qkv_c2;
         a.a = m->dxb; a.out_f32 = m->dq; a.kcache = kc; a.vcache = vc;
         a.stats_in = m->dstats;
+        a.mean_in = mean_buf(cur); a.mean_out = mean_buf(cur ^ 1); cur ^= 1;
         a.pos_ptr = m->dpos; a.n_ctx = T; a.n_head = H;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 2. causal self-attention over positions 0..pos
@@ -564,6 +570,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         memset(&a, 0, sizeof(a));
         a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wo; a.c2 = L.bo;
         a.a = m->datt; a.out_f32 = m->dx; a.out_bf16 = m->dxb; a.ldo = d; a.stats_out = m->dstats;
+        a.mean_in = mean_buf(cur);
         a.pf_ptr = L.wxq_f; a.pf_rows = d; a.pf_k = d;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 4. cross_attn_ln (folded) + query projection
@@ -571,6 +578,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.epi = DE_Q; a.B = B; a.N = d; a.K = d; a.W = L.wxq_f; a.c1 = L.xq_c1; a.c2 = L.xq_c2;
         a.a = m->dxb; a.out_f32 = m->dq; a.ldo = d;
         a.stats_in = m->dstats;
+        a.mean_in = mean_buf(cur); a.mean_out = mean_buf(cur ^ 1); cur ^= 1;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 5. cross-attention over the 1500 cached encoder frames
         WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, xns, m->dpart, m->datt, true, L.wxo, d, d));
@@ -578,6 +586,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         memset(&a, 0, sizeof(a));
         a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wxo; a.c2 = L.bxo;
         a.a = m->datt; a.out_f32 = m->dx; a.out_bf16 = m->dxb; a.ldo = d; a.stats_out = m->dstats;
+        a.mean_in = mean_buf(cur);
         a.pf_ptr = L.w1_f; a.pf_rows = 4 * d; a.pf_k = d;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 7. mlp_ln (folded) + fc1 + GELU
@@ -585,12 +594,14 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.epi = DE_GELU; a.B = B; a.N = 4 * d; a.K = d; a.W = L.w1_f; a.c1 = L.fc1_c1; a.c2 = L.fc1_c2;
         a.a = m->dxb; a.out_bf16 = m->dhid; a.ldo = 4 * d;
         a.stats_in = m->dstats;
+        a.mean_in = mean_buf(cur); a.mean_out = mean_buf(cur ^ 1); cur ^= 1;
         a.pf_ptr = L.w2; a.pf_rows = d; a.pf_k = 4 * d;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 8. fc2 + residual
         memset(&a, 0, sizeof(a));
         a.epi = DE_RESID; a.B = B; a.N = d; a.K = 4 * d; a.W = L.w2; a.c2 = L.b2;
         a.a = m->dhid; a.out_f32 = m->dx; a.out_bf16 = m->dxb; a.ldo = d; a.stats_out = m->dstats;
+        a.mean_in = mean_buf(cur);
         if (l + 1 < D.n_text_layer) { a.pf_ptr = m->dec[l + 1].wqkv_f; a.pf_rows = 3 * d; a.pf_k = d; }
         WM_TRY(wm_dec_gemv(ctx, a));
     }
@@ -599,6 +610,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         memset(&a, 0, sizeof(a));
         a.epi = DE_LOGITS; a.B = B; a.N = D.n_vocab; a.K = d; a.W = m->emb_f; a.c1 = m->logit_c1; a.c2 = m->logit_c2;
         a.a = m->dxb; a.stats_in = m->dstats;
+        a.mean_in = mean_buf(cur); a.mean_out = mean_buf(cur ^ 1);
         a.out_f32 = want_logits ? m->dlogits : nullptr; a.ldo = m->vpad;
         a.argmax = m->dargmax; a.arg_first = arg_first; a.arg_last = arg_last;
         if (mask_first_pos >= 0) {
@@ -612,7 +624,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
 
 int wm_model_embed_first(wm_ctx *ctx, int B) {
     WmModel *m = ctx->model;
-    return wm_dec_embed(ctx, m->dseq, m->dpos, B, m->tok_emb, m->dec_pos, m->dims.n_text_state, m->dx, m->dxb, m->dstats);
+    return wm_dec_embed(ctx, m->dseq, m->dpos, B, m->tok_emb, m->dec_pos, m->dims.n_text_state, m->dx, m->dxb, m->dstats, m->dmean);
 }
 
 int wm_model_close_step(wm_ctx *ctx, int B, int n_prompt, bool write_seq, int *result, int arg_first, bool use_ts) {
@@ -620,5 +632,5 @@ int wm_model_close_step(wm_ctx *ctx, int B, int n_prompt, bool write_seq, int *r
     const WmTsDev t = wm_model_ts_dev(m);
     return wm_argmax_embed(ctx, m->dargmax, m->vpad / 16, B, write_seq ? m->dseq : nullptr, m->dpos, n_prompt, result,
                            arg_first, m->tok_emb, m->dec_pos, m->dims.n_text_state, m->dims.n_text_ctx, m->dx, m->dxb,
-                           m->dstats, use_ts ? &t : nullptr, m->darrive, use_ts ? m->ts_eot : arg_first);
+                           m->dstats, use_ts ? &t : nullptr, m->darrive, use_ts ? m->ts_eot : arg_first, m->dmean);
 }

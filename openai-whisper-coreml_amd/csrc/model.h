@@ -114,7 +114,8 @@ struct WmModel {
     bf16_t *skv = nullptr;    // [L][2][B][H][n_text_ctx][64] self-attention K/V cache
     // decode-step buffers
     float *dx = nullptr;        // [B][d]    decoder residual stream (f32)
-    bf16_t *dxb = nullptr;      // [B][d]    its bf16 copy: the A operand of the LayerNorm-folded GEMVs (WL_TILED order)
+    bf16_t *dxb = nullptr;      // [B][d]    its bf16 copy, MEAN-CENTRED: the A operand of the LayerNorm-folded GEMVs (WL_TILED order)
+    float *dmean = nullptr;     // [2][B]    ping-pong: the rows' LayerNorm means = the centring offsets of dxb
     float *dq = nullptr;        // [16][d]   query (self or cross)
     float *dpart = nullptr;     // [16][H][WM_MAXSPLIT][66] attention partials (m, l, o[64])
     float *dstats = nullptr;    // [B/16][d/16][16][2] LayerNorm partial statistics of the residual stream
@@ -224,6 +225,11 @@ struct DecGemvArgs {
     const float *stats_in; // LayerNorm mode: [B/16][K/16][16][2] partial (sum, sum of squares) per row of the f32 residual,
     int stats_parts;       //                 from the producer of the residual (always K/16 parts; unused ones are zero)
     float *stats_out;      // DE_RESID: [B/16][N/16][16][2] partials of the updated residual (may be null)
+    // mean-centring of the bf16 residual copy (dec_kernels.hip, DecGemvDev::mean_in): [B] f32 each, nullable.
+    // DE_RESID reads the offsets; a LayerNorm-mode launch reads them and writes the rows' new means to mean_out
+    // (the OTHER buffer of a ping-pong pair).
+    const float *mean_in;
+    float *mean_out;
     // outputs
     float *out_f32;        // DE_QKV: q [B][N/3]; DE_Q: [B][ldo]; DE_RESID: residual [B][ldo] (+=); DE_LOGITS: [B][ldo] or null
     bf16_t *out_bf16;      // DE_GELU: [B][ldo]; DE_RESID: bf16 copy of the updated residual (may be null); WL_TILED order
@@ -250,7 +256,7 @@ int wm_ln_fold(wm_ctx *ctx, const bf16_t *W, const float *g, const float *beta, 
                int K, bf16_t *Wf, float *c1, float *c2);
 // x[b] = token_embedding[seq[*pos_ptr][b]] + positional_embedding[*pos_ptr]
 int wm_dec_embed(wm_ctx *ctx, const int *seq, const int *pos_ptr, int B, const bf16_t *emb, const float *pemb,
-                 int d, float *x, bf16_t *xb, float *stats_out);
+                 int d, float *x, bf16_t *xb, float *stats_out, float *mean_buf /*nullable*/);
 // Single-query attention over a K/V cache [B][H][T_stride][64] -> bf16 head outputs att[B][H*64] in WL_TILED order.
 // Keys 0 .. n-1 with n = *pos_ptr + 1 when pos_ptr != null, else n_keys.
 int wm_dec_attn_splits(int B, int H);
@@ -270,7 +276,7 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
 int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
                     int n_prompt, int *result, int arg_first, const bf16_t *emb, const float *pemb, int d, int n_ctx,
                     float *x, bf16_t *xb, float *stats_out, const WmTsDev *ts = nullptr, int *arrive = nullptr,
-                    int fallback_tok = 0);
+                    int fallback_tok = 0, float *mean_buf = nullptr);
 // initial timestamp-rule state of B sequences (before the first sampled token)
 int wm_ts_init(wm_ctx *ctx, const WmTsDev &ts, int B);
 int wm_range_softmax(wm_ctx *ctx, const float *logits, long ldo, int B, int first, int n, float *probs);

@@ -925,3 +925,33 @@ def test_converted_checkpoints_load_and_match_the_oracle(pkg, tmp_path):
         outs.append((xa, lg))
         ctx.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])   # same weights either way
+
+
+def test_layernorm_fold_is_robust_to_a_common_mode_offset(pkg):
+    """The decode GEMVs multiply the RAW bf16 residual (LayerNorm folded into the weights).  bf16 rounding of the raw row
+    scales with |x|, so a common-mode offset of the stream -- which LayerNorm removes exactly -- would leak 2^-9 |offset|
+    of noise per element (measured before the fix: offset 1.0 at std ~0.2 -> logits rel-L2 4.6e-2, offset 10 -> 0.43).
+    The bf16 copy is therefore stored MEAN-CENTRED (offset = the row's previous LayerNorm mean, ping-pong buffers) and the
+    fold uses (mean - offset): the error must not grow with the offset, nor with a massive-activation feature."""
+    dims = dict(R.TINY_DIMS)
+    errs = []
+    for off, outl in ((0.0, 0.0), (3.0, 0.0), (10.0, 0.0), (3.0, 30.0)):
+        sd_np = nontrivial_ln(W.synthetic_state_dict(dims, seed=11))
+        pe = sd_np["decoder.positional_embedding"].copy()
+        pe += off
+        pe[:, 5] += outl
+        sd_np["decoder.positional_embedding"] = pe.astype(np.float32)
+        ctx = pkg.binding.Context(dims)
+        ctx.load_state_dict(sd_np)
+        ctx.finalize()
+        sd = _oracle_weights(ctx, dims)
+        _, mel = mels(ctx, 1, start=3)
+        xa = R.encode(sd, dims, mel).numpy()
+        tok = np.array([[10, 21, 5, 7, 100, 200]], np.int32)
+        e = R.rel_l2(ctx.decode_logits(tok, xa), R.decode_logits(sd, dims, tok, xa).numpy())
+        errs.append(e)
+        assert e <= LOGIT_TOL, (off, outl, e)
+        toks, _ = ctx.transcribe_greedy(np.stack([L.synth_chunk(3)]), [10, 21, 5, 7], 6)     # the graph-replayed path too
+        _check_greedy_against_teacher_forced_oracle(sd, dims, xa, [10, 21, 5, 7], toks)
+        ctx.close()
+    assert max(errs) <= 2.0 * errs[0] + 1e-3, errs
