@@ -308,11 +308,18 @@ __device__ __forceinline__ void gemv_unit_epilogue(const DecGemvDev &p, const Ge
     }
 }
 
-template <int SPW, int TN, int NBLK, int EPI, bool LN>
-__global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1) ? 512 : 1024) void dec_gemv_kernel(DecGemvDev p) {
+// PPW (parts per wave): 1 = every wave owns one K part, all loads up front (the latency shape).  2 = a wave walks TWO
+// parts one after the other (part w, then part w + NW) in the same registers: half the waves per workgroup for the same
+// K split, so the 16-part K = 4d product runs as an 8-wave workgroup of <= 128 VGPRs that sits TWO per CU -- at more
+// than one batch block its (tile, block) grid then fits one residency round of the chip instead of two (one extra L2
+// round trip inside the workgroup, a whole kernel time saved).  The parts, their MFMA chains and the order they are
+// added in are the same: bit-identical results.
+template <int SPW, int TN, int NBLK, int EPI, bool LN, int PPW = 1>
+__global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512 : 1024) void dec_gemv_kernel(DecGemvDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NU = TN * NBLK;
     const int NW = blockDim.x >> 6;
+    const int NP = NW * PPW;  // K parts
     // Workgroup id -> (tile group, batch group): ids 8q .. 8q+7 are tile groups 8(q / G) .. +7 of batch group q % G, so
     // the workgroups of a tile group are dispatched back to back AND on the same XCD (id % 8): the later ones read the
     // weights from the L2 the first one filled -- one HBM stream per tile.  (G == 1: id == tile group.)
@@ -327,7 +334,7 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1) ? 512 : 1024) vo
         return;
     }
     float *red = (float *)smem;
-    float *st = red + NW * NU * 256 + (threadIdx.x >> 6) * 32;  // wave-private
+    float *st = red + NP * NU * 256 + (threadIdx.x >> 6) * 32;  // wave-private
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nrow = lane & 15;
     const int tile0 = tg * TN;
@@ -336,27 +343,33 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1) ? 512 : 1024) vo
     // ---- 1. every load of the workgroup in flight: weights (fragment-tiled: k-step s of n-tile t is the contiguous
     // KiB at ((t * K/32 + s) * 64 + lane) * 8 -- one perfectly coalesced dwordx4 per lane per step) ...
     u32x4 wf[TN][SPW];
+    auto load_wf = [&](int part) {
 #pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        const int tc = tile0 + t < p.n_tiles ? tile0 + t : p.n_tiles - 1;  // clamped: unconditional loads
-        const bf16_t *wp = p.W + (((long)tc * (p.K >> 5) + (long)wave * SPW) * 64 + lane) * 8;
+        for (int t = 0; t < TN; ++t) {
+            const int tc = tile0 + t < p.n_tiles ? tile0 + t : p.n_tiles - 1;  // clamped: unconditional loads
+            const bf16_t *wp = p.W + (((long)tc * (p.K >> 5) + (long)part * SPW) * 64 + lane) * 8;
 #pragma unroll
-        for (int u = 0; u < SPW; ++u) wf[t][u] = __builtin_nontemporal_load((const u32x4 *)(wp + u * 512));
-    }
+            for (int u = 0; u < SPW; ++u) wf[t][u] = __builtin_nontemporal_load((const u32x4 *)(wp + u * 512));
+        }
+    };
+    load_wf(wave);
     // ... the activation fragments of its batch blocks: the activations are stored fragment-tiled exactly like the
     // weights (block of 16 rows x k-step = one contiguous KiB in MFMA A-operand order, written that way by their
     // producers), so this is ONE perfectly coalesced dwordx4 per lane per step too -- a row-major [B][K] buffer costs
     // 16 half-used cache lines per wave-load and twice the L2 -> CU traffic.  Rows past B inside the last block hold
     // stale data: an MFMA output row depends on its own A row only, and those rows are never stored ...
     u32x4 af[NBLK][SPW];
+    auto load_af = [&](int part) {
 #pragma unroll
-    for (int j = 0; j < NBLK; ++j) {
-        const int blk = (bb >> 4) + j;
-        const int blkc = blk * 16 < p.B ? blk : (bb >> 4);  // a missing second block re-reads the first (never used)
-        const bf16_t *ap = p.a + (((long)blkc * (p.K >> 5) + (long)wave * SPW) * 64 + lane) * 8;
+        for (int j = 0; j < NBLK; ++j) {
+            const int blk = (bb >> 4) + j;
+            const int blkc = blk * 16 < p.B ? blk : (bb >> 4);  // a missing second block re-reads the first (never used)
+            const bf16_t *ap = p.a + (((long)blkc * (p.K >> 5) + (long)part * SPW) * 64 + lane) * 8;
 #pragma unroll
-        for (int u = 0; u < SPW; ++u) af[j][u] = *(const u32x4 *)(ap + u * 512);
-    }
+            for (int u = 0; u < SPW; ++u) af[j][u] = *(const u32x4 *)(ap + u * 512);
+        }
+    };
+    load_af(wave);
     // ... and the epilogue operands of the (tile, block) unit this wave will finish: unit u = j * TN + t -> wave u % NW
     int pos = 0;
     unsigned mword0 = 0u, mword1 = 0u;
@@ -378,25 +391,33 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1) ? 512 : 1024) vo
         mword1 = p.mask[p.mask_words + (nc >> 5)];
     }
 
-    // ---- 2. products of this wave's K range: an activation fragment feeds the TN tiles
+    // ---- 2. products of this wave's K part(s): an activation fragment feeds the TN tiles
+    // ---- 3. cross-wave (split-K) reduction through LDS, one slot per part; statistics of this wave's unit meanwhile
     f32x4 acc[NBLK][TN];
 #pragma unroll
-    for (int j = 0; j < NBLK; ++j)
-#pragma unroll
-        for (int t = 0; t < TN; ++t) {
-            f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < SPW; ++u)
-                a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[j][u]),
-                                                             __builtin_bit_cast(bf16x8, wf[t][u]), a4, 0, 0, 0);
-            acc[j][t] = a4;
+    for (int pp = 0; pp < PPW; ++pp) {
+        const int part = wave + pp * NW;
+        if (pp > 0) {  // second part: same registers, requested once the first part's products have read them
+            load_wf(part);
+            load_af(part);
         }
-    // ---- 3. cross-wave (split-K) reduction through LDS; statistics of this wave's unit meanwhile
-    if (NU > 1 || wave != 0) {  // a single unit is finished by wave 0 from its own registers
 #pragma unroll
         for (int j = 0; j < NBLK; ++j)
 #pragma unroll
-            for (int t = 0; t < TN; ++t) *(f32x4 *)(red + ((wave * NU + j * TN + t) * 64 + lane) * 4) = acc[j][t];
+            for (int t = 0; t < TN; ++t) {
+                f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < SPW; ++u)
+                    a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[j][u]),
+                                                                 __builtin_bit_cast(bf16x8, wf[t][u]), a4, 0, 0, 0);
+                acc[j][t] = a4;
+            }
+        if (PPW > 1 || NU > 1 || wave != 0) {  // (one part per wave, one unit: wave 0 finishes it from its own registers)
+#pragma unroll
+            for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+                for (int t = 0; t < TN; ++t) *(f32x4 *)(red + ((part * NU + j * TN + t) * 64 + lane) * 4) = acc[j][t];
+        }
     }
     if (has_unit) gemv_unit_stats<EPI, LN>(p, ops, st, lane, utile, ub0);
     __syncthreads();
@@ -415,8 +436,8 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1) ? 512 : 1024) vo
                 mword1 = p.mask[p.mask_words + (nc >> 5)];
             }
         }
-        f32x4 sum = NU == 1 ? acc[0][0] : *(const f32x4 *)(red + ((0 * NU + u) * 64 + lane) * 4);
-        for (int w = 1; w < NW; ++w) sum += *(const f32x4 *)(red + ((w * NU + u) * 64 + lane) * 4);
+        f32x4 sum = (NU == 1 && PPW == 1) ? acc[0][0] : *(const f32x4 *)(red + ((0 * NU + u) * 64 + lane) * 4);
+        for (int w = 1; w < NP; ++w) sum += *(const f32x4 *)(red + ((w * NU + u) * 64 + lane) * 4);
         gemv_unit_epilogue<EPI, LN>(p, ops, sum, st, tile, b0, lane, pos, mword0, mword1);
     }
 }
@@ -860,8 +881,17 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(void *dst, int is_bf16,
 }
 
 template <int SPW, int EPI, bool LN>
-int launch_gemv_shape(wm_ctx *ctx, const DecGemvDev &p, int tn, int nblk, int nw, int grid) {
+int launch_gemv_shape(wm_ctx *ctx, const DecGemvDev &p, int tn, int nblk, int nw, int grid, int ppw) {
     hipStream_t s = ctx->stream;
+    if (ppw == 2) {  // 16 K parts on 8 waves (the K = 4d residual products at more than one batch block)
+        constexpr bool TWO = !LN && EPI == DE_RESID && SPW >= 6 && SPW <= 10;
+        if (!TWO || tn != 1 || nblk != 1 || nw % 2) { wm_set_error("dec_gemv: no two-part kernel for this shape"); return WM_ERR_INVALID; }
+        const int w2 = nw / 2;
+        const size_t lds2 = (size_t)nw * 1024 + (size_t)w2 * 32 * 4;
+        dec_gemv_kernel<TWO ? SPW : 6, 1, 1, TWO ? EPI : DE_RESID, TWO ? LN : false, 2><<<grid, w2 * 64, lds2, s>>>(p);
+        WM_HIP(hipGetLastError());
+        return WM_OK;
+    }
     const size_t lds = (size_t)nw * tn * nblk * 1024 + (size_t)nw * 32 * 4;
     const int th = nw * 64;
     constexpr bool WIDE = LN && (EPI == DE_QKV || EPI == DE_GELU || EPI == DE_LOGITS) && SPW <= 6;
@@ -875,15 +905,15 @@ int launch_gemv_shape(wm_ctx *ctx, const DecGemvDev &p, int tn, int nblk, int nw
 }
 
 template <int EPI, bool LN>
-int launch_gemv(wm_ctx *ctx, const DecGemvDev &p, int spw, int tn, int nblk, int nw, int grid) {
+int launch_gemv(wm_ctx *ctx, const DecGemvDev &p, int spw, int tn, int nblk, int nw, int grid, int ppw) {
     switch (spw) {
-        case 2: return launch_gemv_shape<2, EPI, LN>(ctx, p, tn, nblk, nw, grid);
-        case 4: return launch_gemv_shape<4, EPI, LN>(ctx, p, tn, nblk, nw, grid);
-        case 5: return launch_gemv_shape<5, EPI, LN>(ctx, p, tn, nblk, nw, grid);
-        case 6: return launch_gemv_shape<6, EPI, LN>(ctx, p, tn, nblk, nw, grid);
-        case 8: return launch_gemv_shape<8, EPI, LN>(ctx, p, tn, nblk, nw, grid);
-        case 10: return launch_gemv_shape<10, EPI, LN>(ctx, p, tn, nblk, nw, grid);
-        case 12: return launch_gemv_shape<12, EPI, LN>(ctx, p, tn, nblk, nw, grid);
+        case 2: return launch_gemv_shape<2, EPI, LN>(ctx, p, tn, nblk, nw, grid, ppw);
+        case 4: return launch_gemv_shape<4, EPI, LN>(ctx, p, tn, nblk, nw, grid, ppw);
+        case 5: return launch_gemv_shape<5, EPI, LN>(ctx, p, tn, nblk, nw, grid, ppw);
+        case 6: return launch_gemv_shape<6, EPI, LN>(ctx, p, tn, nblk, nw, grid, ppw);
+        case 8: return launch_gemv_shape<8, EPI, LN>(ctx, p, tn, nblk, nw, grid, ppw);
+        case 10: return launch_gemv_shape<10, EPI, LN>(ctx, p, tn, nblk, nw, grid, ppw);
+        case 12: return launch_gemv_shape<12, EPI, LN>(ctx, p, tn, nblk, nw, grid, ppw);
         default: wm_set_error("dec_gemv: unsupported k-steps per wave %d", spw); return WM_ERR_INVALID;
     }
 }
@@ -964,6 +994,9 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     int tn = 1, nblk = 1;
     pick_shape(a.epi, ln, spw, a.B, p.n_tiles, &tn, &nblk);
     p.bgroups = ((a.B + 15) / 16 + nblk - 1) / nblk;
+    // the 16-part K = 4d residual product at more than one batch block: two parts per wave, 8-wave workgroups (two per CU)
+    static const bool no_ppw = getenv("WM_GEMV_NO_PPW2") != nullptr;
+    const int ppw = (!no_ppw && !ln && a.epi == DE_RESID && nw == 16 && a.B > 16 && spw >= 6 && spw <= 10) ? 2 : 1;
     p.n_tg = (p.n_tiles + tn - 1) / tn;
     p.n_tg_pad = p.bgroups > 1 ? (p.n_tg + 7) / 8 * 8 : p.n_tg;  // (tile group, batch group) decode needs rows of 8
     int grid = p.n_tg_pad * p.bgroups;
@@ -977,27 +1010,27 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     switch (a.epi * 2 + (ln ? 1 : 0)) {
         case DE_QKV * 2 + 1: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_qkv", ctx->stream);
-            return launch_gemv<DE_QKV, true>(ctx, p, spw, tn, nblk, nw, grid);
+            return launch_gemv<DE_QKV, true>(ctx, p, spw, tn, nblk, nw, grid, ppw);
         }
         case DE_Q * 2 + 1: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_q", ctx->stream);
-            return launch_gemv<DE_Q, true>(ctx, p, spw, tn, nblk, nw, grid);
+            return launch_gemv<DE_Q, true>(ctx, p, spw, tn, nblk, nw, grid, ppw);
         }
         case DE_GELU * 2 + 1: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_fc1", ctx->stream);
-            return launch_gemv<DE_GELU, true>(ctx, p, spw, tn, nblk, nw, grid);
+            return launch_gemv<DE_GELU, true>(ctx, p, spw, tn, nblk, nw, grid, ppw);
         }
         case DE_LOGITS * 2 + 1: {
             WmProfScope ps(&ctx->prof, "dec_gemv_ln_logits", ctx->stream);
-            return launch_gemv<DE_LOGITS, true>(ctx, p, spw, tn, nblk, nw, grid);
+            return launch_gemv<DE_LOGITS, true>(ctx, p, spw, tn, nblk, nw, grid, ppw);
         }
         case DE_RESID * 2: {
             WmProfScope ps(&ctx->prof, a.K > a.N ? "dec_gemv_fc2" : "dec_gemv_attn_out", ctx->stream);
-            return launch_gemv<DE_RESID, false>(ctx, p, spw, tn, nblk, nw, grid);
+            return launch_gemv<DE_RESID, false>(ctx, p, spw, tn, nblk, nw, grid, ppw);
         }
         case DE_Q * 2: {
             WmProfScope ps(&ctx->prof, "dec_gemv_plain", ctx->stream);
-            return launch_gemv<DE_Q, false>(ctx, p, spw, tn, nblk, nw, grid);
+            return launch_gemv<DE_Q, false>(ctx, p, spw, tn, nblk, nw, grid, ppw);
         }
         default:
             wm_set_error("dec_gemv: unsupported (epilogue %d, LayerNorm %d) pair", a.epi, (int)ln);

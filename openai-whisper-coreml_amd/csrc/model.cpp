@@ -524,6 +524,9 @@ int wm_model_decode_begin(wm_ctx *ctx, int B) {
     WmModel *m = ctx->model;
     WM_REQUIRE(m && m->finalized, WM_ERR_STATE, "model weights not finalised (wm_finalize)");
     WM_REQUIRE(B >= 1 && B <= WM_DEC_MAXB, WM_ERR_INVALID, "decode batch must be 1..%d", WM_DEC_MAXB);
+    // the arrival counter of the arg-max workgroups is zero between launches; a decode that was abandoned half way
+    // (an error in the middle of a step) must not leave the next one with a stale count
+    WM_HIP(hipMemsetAsync(m->darrive, 0, sizeof(int), ctx->stream));
     return WM_OK;
 }
 
