@@ -219,6 +219,8 @@ def main():
     gathered = None
     seen = []   # (steps in the group, tokens) of every finished group: compared after the timed region
 
+    t_origin = [time.perf_counter()]
+
     def run_steps(n_steps):
         """n_steps batches of nb chunks as decode groups, S in flight; returns summed stage ms of all groups."""
         nonlocal gathered
@@ -228,8 +230,13 @@ def main():
 
         def run_group(w, g, k):
             c = ctxs[w]
+            ta = time.perf_counter()
             toks, lens = c.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE,
                                              pcm_dtype=B.WM_I16, B=nb * k)
+            if os.environ.get("WM_BENCH_TRACE"):   # per-group host timeline (debugging lane overlap)
+                print("trace lane %d group %d (%d chunks): call %.1f..%.1f ms, stages %s" % (
+                    w, g, nb * k, (ta - t_origin[0]) * 1e3, (time.perf_counter() - t_origin[0]) * 1e3,
+                    np.round(c.last_stage_ms(), 1)), file=sys.stderr)
             with lock:
                 stage_sum[:] += c.last_stage_ms()
                 seen.append((k, toks))
@@ -251,6 +258,7 @@ def main():
     run_steps(max(args.warmup, S * F) if args.warmup > 0 else 0)   # >= one full round: every context warmed (graph captured)
     sync_all()
     t0 = time.perf_counter()
+    t_origin[0] = t0
     stage = run_steps(args.steps)
     sync_all()
     dt = time.perf_counter() - t0

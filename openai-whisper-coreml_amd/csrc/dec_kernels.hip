@@ -19,6 +19,8 @@
 //   * the decode position lives in HBM (*pos_ptr) and is advanced by the arg-max kernel, so
 //     ONE captured hipGraph of the whole step replays for every position.
 #include <stdlib.h>
+
+#include <atomic>
 #include <string.h>
 
 #include "model.h"
@@ -941,6 +943,16 @@ int wm_dec_gemv_split(int K, int *spw) {
 // Small batches (one block): one tile per workgroup, as many workgroups as tiles (latency).  Large batches: two blocks
 // per workgroup and, for the wide matrices, 2 or 4 tiles per workgroup so that the grid stays near one round of the chip
 // and an activation fragment is fetched once per TN products.
+// L2 warm-up of the NEXT launch's weight matrix by extra workgroups of the current one: a latency lever for a decode
+// group of one batch block (the next GEMV finds its weights in L2: ~1 us off a 4-5 us launch).  Larger groups are
+// throughput-bound and run beside other groups; there the extra workgroups only take slots and bandwidth (measured,
+// 3 groups of 56 chunks: 1978 -> 2007 audio-s/s without).  WM_PREFETCH_MAX_B overrides the threshold, WM_NO_PREFETCH: off.
+static bool pf_enabled(int B) {
+    static const bool no_pf = getenv("WM_NO_PREFETCH") != nullptr;
+    static const int max_b = getenv("WM_PREFETCH_MAX_B") ? atoi(getenv("WM_PREFETCH_MAX_B")) : 16;
+    return !no_pf && B <= max_b;
+}
+
 static void pick_shape(int epi, bool ln, int spw, int B, int n_tiles, int *tn, int *nblk) {
     static const int env_tn = getenv("WM_GEMV_TN") ? atoi(getenv("WM_GEMV_TN")) : 0;
     static const int env_nb = getenv("WM_GEMV_NBLK") ? atoi(getenv("WM_GEMV_NBLK")) : 0;
@@ -1000,8 +1012,7 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     p.n_tg = (p.n_tiles + tn - 1) / tn;
     p.n_tg_pad = p.bgroups > 1 ? (p.n_tg + 7) / 8 * 8 : p.n_tg;  // (tile group, batch group) decode needs rows of 8
     int grid = p.n_tg_pad * p.bgroups;
-    static const bool no_pf = getenv("WM_NO_PREFETCH") != nullptr;
-    if (!no_pf && a.pf_ptr && a.pf_rows >= 16 && grid % 8 == 0) {
+    if (pf_enabled(a.B) && a.pf_ptr && a.pf_rows >= 16 && grid % 8 == 0) {
         p.pf_ptr = (const char *)a.pf_ptr;
         p.pf_tile_bytes = 16L * a.pf_k * 2;
         p.pf_tiles = a.pf_rows / 16;
@@ -1079,7 +1090,6 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
     WM_REQUIRE(nsplit == 1 || part != nullptr, WM_ERR_INVALID, "dec_attention: split launch without a partials buffer");
     {
         WmProfScope ps(&ctx->prof, cross ? "dec_attn_cross" : "dec_attn_self", ctx->stream);
-        static const bool no_pf = getenv("WM_NO_PREFETCH") != nullptr;
         // 8 streams x 4 loads: ~90-120 VGPRs, so two workgroups (or a GEMV of another decode group) share a CU; at most
         // 256 workgroups walk the pairs.  Measured alone at B = 8 / 32 / 64: 12.5-13.8 / 41 / 75 us (4.6-4.9 / 6.0 /
         // 6.5 TB/s); under three-way concurrency the stream saturates at 6.7-7.0 TB/s.  WM_XATTN_WGS: workgroup cap (A/B).
@@ -1092,7 +1102,7 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
         }
         int gx = n_wg;
         long tile_bytes = 0;
-        if (!no_pf && pf_ptr && nsplit == 1 && gx % 8 == 0 && pf_rows >= 16) {
+        if (pf_enabled(B) && pf_ptr && nsplit == 1 && gx % 8 == 0 && pf_rows >= 16) {
             tile_bytes = 16L * pf_k * 2;
             gx += pf_rows / 16;
         }
@@ -1107,7 +1117,21 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
                 q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, 8, B * H, g, nullptr, 0, wpw);
         } else {
             dim3 grid(gx, nsplit);
-            dec_rows_attn_kernel<8, 4, true><<<grid, (8 / nsplit) * 64, 0, ctx->stream>>>(
+            // ONE cross-attention workgroup per CU, chip-wide: a workgroup reserves more than half of the CU's 160 KB of
+            // LDS (it uses 2 KB), so the cross-attention launches of the decode groups in flight take the CUs one after
+            // the other instead of side by side.  A single launch already saturates the HBM (6.4 TB/s alone); a second
+            // one beside it adds no bandwidth but fills the SIMDs' wave slots / VGPRs for the whole launch (persistent
+            // workgroups), and the other groups' GEMVs -- which fit beside ONE such workgroup, LDS included (<= 66 KB) --
+            // wait.  Measured, 3 groups in flight: 1920 -> 1966 audio-s/s (20 steps), 2014 -> 2118 (72 steps, decode stage
+            // 0.74 -> 0.79 of the HBM peak).  WM_XATTN_LDS_PAD=<bytes> overrides (0: off).
+            static const int lds_pad = getenv("WM_XATTN_LDS_PAD") ? atoi(getenv("WM_XATTN_LDS_PAD")) : 84 * 1024;
+            static std::atomic<bool> pad_set[64];  // per device (wm_multi: one process, every GPU of the node)
+            if (lds_pad > 0 && !pad_set[ctx->device & 63].load(std::memory_order_acquire)) {
+                WM_HIP(hipFuncSetAttribute((const void *)dec_rows_attn_kernel<8, 4, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad));
+                pad_set[ctx->device & 63].store(true, std::memory_order_release);
+            }
+            dec_rows_attn_kernel<8, 4, true><<<grid, (8 / nsplit) * 64, nsplit == 1 ? lds_pad : 0, ctx->stream>>>(
                 q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, nsplit, B * H, n_wg, (const char *)pf_ptr,
                 tile_bytes, 0);
         }
@@ -1126,10 +1150,9 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
     WM_REQUIRE(T_stride <= ATT_MAXK && n_keys <= ATT_MAXK && (pos_ptr || n_keys >= 1), WM_ERR_INVALID,
                "dec_self_attention: 1..%d keys", ATT_MAXK);
     WmProfScope ps(&ctx->prof, "dec_attn_self", ctx->stream);
-    static const bool no_pf = getenv("WM_NO_PREFETCH") != nullptr;
     int gx = B * H;
     long tile_bytes = 0;
-    if (!no_pf && pf_ptr && gx % 8 == 0 && pf_rows >= 16) {
+    if (pf_enabled(B) && pf_ptr && gx % 8 == 0 && pf_rows >= 16) {
         tile_bytes = 16L * pf_k * 2;
         gx += pf_rows / 16;
     }

@@ -52,6 +52,18 @@ def main():
         print("%-44s %8d %10.2f %9.2f %9.2f %6.2f" % (n, len(v), sum(v) / 1e3, np.mean(v), min(v), 100 * sum(v) / tot))
     for s in big:
         print("lane stream %d busy %.1f%% of the window" % (s, 100 * busy[s] / (w1 - w0)))
+    # how many cross-attention launches (the HBM-saturating kernel) are in flight over the window
+    ev = []
+    for n, s, a, b in dec:
+        if a >= w0 and b <= w1 and s in big and is_x(n):
+            ev += [(a, 1), (b, -1)]
+    ev.sort()
+    hist, cur, last = {}, 0, w0
+    for t, dlt in ev:
+        hist[cur] = hist.get(cur, 0) + (t - last)
+        cur, last = cur + dlt, t
+    hist[cur] = hist.get(cur, 0) + (w1 - last)
+    print("cross-attention launches in flight: " + ", ".join("%d: %.1f%%" % (k, 100 * v / (w1 - w0)) for k, v in sorted(hist.items())))
     nx = sum(len(v) for n, v in fam.items() if is_x(n))
     d, L, V = 1280, 32, 51865
     layers = nx                                     # one cross-attention launch per (lane, layer, position)
