@@ -23,6 +23,12 @@
 
 #include "model.h"
 
+// No implicit FMA contraction in this file: the two tile shapes (and their different epilogue code paths) must round
+// every output identically -- whether `gelu(v) + pos` or `c + (acc + bias)` became an FMA used to depend on the
+// surrounding code (tests: the 256 tile is bitwise equal to the 128 tile, kernel by kernel and on a whole model).
+// Every FMA that is wanted is written as fmaf().
+#pragma clang fp contract(off)
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -289,13 +295,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
     const int srow = tid >> 3, pch = tid & 7;
     const bf16_t *a_src[4];
     const bf16_t *w_src[4];
+    const unsigned arpb = p.a_rpb > 0x7fffffffL ? 0x7fffffffu : (unsigned)p.a_rpb;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = i * 32 + srow;
         const int lch = pch ^ (row & 7);
-        long m = m0 + row;
-        if (m > p.M - 1) m = p.M - 1;  // clamp: tail rows are masked in the epilogue
-        a_src[i] = p.A + (m / p.a_rpb) * p.a_bstride + (m % p.a_rpb) * p.a_rstride + lch * 8;
+        unsigned m = (unsigned)(m0 + row);
+        if (m > (unsigned)(p.M - 1)) m = (unsigned)(p.M - 1);  // clamp: tail rows are masked in the epilogue
+        const unsigned aq = m / arpb, ar = m - aq * arpb;  // 32-bit: see the 256 kernel
+        a_src[i] = p.A + (long)aq * p.a_bstride + (long)ar * p.a_rstride + lch * 8;
         long n = n0 + row;
         if (n > p.N - 1) n = p.N - 1;
         w_src[i] = p.W + n * (long)p.K + lch * 8;
@@ -416,13 +424,17 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
     const int lch8 = (pch ^ (srow & 7)) * 8;
     const bf16_t *a_src[2][2];  // [sub][pass]
     const bf16_t *w_src[2][2];
+    const unsigned arpb = p.a_rpb > 0x7fffffffL ? 0x7fffffffu : (unsigned)p.a_rpb;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            long m = m0 + i * 128 + sub * 64 + srow;  // pass i = wave row i
-            if (m > p.M - 1) m = p.M - 1;             // clamp: tail rows are masked in the epilogue
-            a_src[sub][i] = p.A + (m / p.a_rpb) * p.a_bstride + (m % p.a_rpb) * p.a_rstride + lch8;
+            unsigned m = (unsigned)(m0 + i * 128 + sub * 64 + srow);  // pass i = wave row i
+            if (m > (unsigned)(p.M - 1)) m = (unsigned)(p.M - 1);     // clamp: tail rows are masked in the epilogue
+            // 32-bit row -> (batch, row) division: the 64-bit one is ~300 VALU instructions, and four of them per thread
+            // were 1.4 us of a 28-us K = 1280 tile (measured with in-kernel timestamps)
+            const unsigned aq = m / arpb, ar = m - aq * arpb;
+            a_src[sub][i] = p.A + (long)aq * p.a_bstride + (long)ar * p.a_rstride + lch8;
             long n = n0 + (2 * i + (srow >> 5)) * 64 + sub * 32 + (srow & 31);  // unit-row -> (wave col, row)
             if (n > p.N - 1) n = p.N - 1;
             w_src[sub][i] = p.W + n * (long)p.K + lch8;
@@ -580,7 +592,7 @@ static void launch_gemm(const GemmDev &p, bool big, int grid, hipStream_t s) {
 
 int wm_gemm(wm_ctx *ctx, const GemmArgs &g) {
     WM_REQUIRE(g.K % BK == 0 && g.K >= BK, WM_ERR_INVALID, "gemm: K=%d must be a multiple of %d", g.K, BK);
-    WM_REQUIRE(g.M > 0 && g.N > 0, WM_ERR_INVALID, "gemm: empty problem");
+    WM_REQUIRE(g.M > 0 && g.N > 0 && g.M < (1 << 30) && g.a_rpb > 0 && g.c_rpb > 0, WM_ERR_INVALID, "gemm: bad problem size");
     GemmDev p;
     p.A = g.A; p.a_rpb = g.a_rpb; p.a_bstride = g.a_bstride; p.a_rstride = g.a_rstride;
     p.W = g.W; p.bias = g.bias; p.C = g.C;

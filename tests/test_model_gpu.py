@@ -143,6 +143,37 @@ def test_committed_model_golden(pkg):
     ctx.close()
 
 
+def test_whole_model_256_tile_is_bitwise_equal_to_the_128_tile(pkg):
+    """Every epilogue of the 256 x 256 encoder GEMM (row-contiguous stores straight from C^T accumulators, permuted W
+    staging, the V^T waves of the QKV projection that keep the other operand order, conv2 + positional embedding,
+    the cross-K/V scatter) against the 128 x 128 kernel on a whole model: both accumulate every dot product in the
+    same order, so encoder output, teacher-forced logits (through the cross-K/V cache) and greedy tokens must be
+    identical bit for bit."""
+    import ctypes
+    dims = dict(R.TINY_DIMS)
+    ctx = pkg.binding.Context(dims, debug=True)
+    ctx.lib.wmdbg_set_gemm_tile.argtypes = [ctypes.c_int]
+    try:
+        ctx.init_synthetic(23)
+        ctx.finalize()
+        pcm = tones(3)
+        mel = ctx.logmel(pcm, out_dtype=np.float32)
+        toks = np.array([[1, 7, 300, 1023], [4, 4, 900, 17], [9, 2, 2, 511]], np.int32)
+        outs = []
+        for tile in (128, 256):
+            assert ctx.lib.wmdbg_set_gemm_tile(tile) == 0
+            xa = ctx.encode_mel(mel)
+            lg = ctx.decode_logits(toks, xa)
+            gen, lens = ctx.transcribe_greedy(pcm, [1, 2], 6)
+            outs.append((xa, lg, gen))
+        assert np.isfinite(outs[0][0]).all() and np.abs(outs[0][0]).max() > 0
+        for a, b in zip(outs[0], outs[1]):
+            assert np.array_equal(a, b)
+    finally:
+        ctx.lib.wmdbg_set_gemm_tile(0)
+        ctx.close()
+
+
 def test_encoder_batch_independence(tiny):
     dims, _, _, ctx = tiny
     _, mel = mels(ctx, 3)
