@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libwhisper_mi355x.so")
+LIB_PATH = os.environ.get("WM_LIB_PATH") or os.path.join(HERE, "libwhisper_mi355x.so")   # WM_LIB_PATH: A/B builds
 # the product objects + the wmdbg_* kernel test hooks (include/whisper_mi355x_debug.h): tests / tools only
 DEBUG_LIB_PATH = os.path.join(HERE, "libwhisper_mi355x_dbg.so")
 

@@ -351,7 +351,14 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
             const int tc = tile0 + t < p.n_tiles ? tile0 + t : p.n_tiles - 1;  // clamped: unconditional loads
             const bf16_t *wp = p.W + (((long)tc * (p.K >> 5) + (long)part * SPW) * 64 + lane) * 8;
 #pragma unroll
+            // plain (cacheable) loads, not non-temporal ones: a decode group reads a weight matrix once per position, but the
+            // groups in flight walk the same layers a few layers apart, and the second and third reader find the matrix in the
+            // 256 MB Infinity Cache (measured, 3 groups of 56: 2000 -> 2055 audio-s/s; one group alone: no difference)
+#ifdef WM_GEMV_W_NONTEMPORAL
             for (int u = 0; u < SPW; ++u) wf[t][u] = __builtin_nontemporal_load((const u32x4 *)(wp + u * 512));
+#else
+            for (int u = 0; u < SPW; ++u) wf[t][u] = *(const u32x4 *)(wp + u * 512);
+#endif
         }
     };
     load_wf(wave);
