@@ -541,6 +541,9 @@ __global__ __launch_bounds__(256) void dec_embed_kernel(const int *__restrict__ 
 // of the decode group (bit-level batch invariance; the round-1 kernels switched arithmetic with the batch).
 // NT: non-temporal loads (a cross-attention cache row is read once per step).
 constexpr int ATT_MAXK = 1536;
+#ifndef WM_XATTN_NT
+#define WM_XATTN_NT true  // cross-attention K/V rows: non-temporal loads (A/B builds: -DWM_XATTN_NT=false)
+#endif
 
 // merged head-output element e of a pair from its NS stream partials (m, l, o): the one place the merge is written
 template <int NS>
@@ -1120,7 +1123,7 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
             int wpw = (units + 255) / 256;
             wpw = wpw < 1 ? 1 : (wpw > 8 ? 8 : wpw);
             const int g = (units + wpw - 1) / wpw;
-            dec_rows_attn_kernel<8, 4, true><<<g, wpw * 64, 0, ctx->stream>>>(
+            dec_rows_attn_kernel<8, 4, WM_XATTN_NT><<<g, wpw * 64, 0, ctx->stream>>>(
                 q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, 8, B * H, g, nullptr, 0, wpw);
         } else {
             dim3 grid(gx, nsplit);
@@ -1134,11 +1137,11 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
             static const int lds_pad = getenv("WM_XATTN_LDS_PAD") ? atoi(getenv("WM_XATTN_LDS_PAD")) : 84 * 1024;
             static std::atomic<bool> pad_set[64];  // per device (wm_multi: one process, every GPU of the node)
             if (lds_pad > 0 && !pad_set[ctx->device & 63].load(std::memory_order_acquire)) {
-                WM_HIP(hipFuncSetAttribute((const void *)dec_rows_attn_kernel<8, 4, true>,
+                WM_HIP(hipFuncSetAttribute((const void *)dec_rows_attn_kernel<8, 4, WM_XATTN_NT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad));
                 pad_set[ctx->device & 63].store(true, std::memory_order_release);
             }
-            dec_rows_attn_kernel<8, 4, true><<<grid, (8 / nsplit) * 64, nsplit == 1 ? lds_pad : 0, ctx->stream>>>(
+            dec_rows_attn_kernel<8, 4, WM_XATTN_NT><<<grid, (8 / nsplit) * 64, nsplit == 1 ? lds_pad : 0, ctx->stream>>>(
                 q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, nsplit, B * H, n_wg, (const char *)pf_ptr,
                 tile_bytes, 0);
         }

@@ -64,6 +64,20 @@ def main():
         cur, last = cur + dlt, t
     hist[cur] = hist.get(cur, 0) + (w1 - last)
     print("cross-attention launches in flight: " + ", ".join("%d: %.1f%%" % (k, 100 * v / (w1 - w0)) for k, v in sorted(hist.items())))
+    # how far apart the lanes are in the layer sequence: cumulative cross-attention launches (one per layer-step) of every
+    # lane at the start of each launch of the first lane
+    import bisect
+    starts = {s: [a for n, ss, a, b in dec if ss == s and is_x(n) and w0 <= a <= w1] for s in big}
+    ref = sorted(big)[0]
+    lags = []
+    for i, t in enumerate(starts[ref]):
+        for s in big:
+            if s != ref:
+                lags.append(bisect.bisect_left(starts[s], t) - i)
+    if lags:
+        lags = np.array(lags)
+        print("lane lag vs first lane in layer-steps: mean %.1f, |lag| median %.1f, p90 %.1f, max %d" % (
+            lags.mean(), np.median(np.abs(lags)), np.percentile(np.abs(lags), 90), np.abs(lags).max()))
     nx = sum(len(v) for n, v in fam.items() if is_x(n))
     d, L, V = 1280, 32, 51865
     layers = nx                                     # one cross-attention launch per (lane, layer, position)
