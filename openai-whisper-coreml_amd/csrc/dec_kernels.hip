@@ -1100,9 +1100,10 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
     WM_REQUIRE(nsplit == 1 || part != nullptr, WM_ERR_INVALID, "dec_attention: split launch without a partials buffer");
     {
         WmProfScope ps(&ctx->prof, cross ? "dec_attn_cross" : "dec_attn_self", ctx->stream);
-        // 8 streams x 4 loads: ~90-120 VGPRs, so two workgroups (or a GEMV of another decode group) share a CU; at most
-        // 256 workgroups walk the pairs.  Measured alone at B = 8 / 32 / 64: 12.5-13.8 / 41 / 75 us (4.6-4.9 / 6.0 /
-        // 6.5 TB/s); under three-way concurrency the stream saturates at 6.7-7.0 TB/s.  WM_XATTN_WGS: workgroup cap (A/B).
+        // 8 streams x 4 loads = 126 VGPRs: an 8-wave GEMV workgroup of another decode group fits beside one of these on a
+        // CU (a second cross-attention workgroup does not: LDS reservation below); at most 256 workgroups -- one per CU --
+        // walk the pairs, balanced (56 chunks x 20 heads = 224 workgroups x 5 pairs).  Measured alone at B = 8 / 56 / 128:
+        // 12.8 / 67 / 144 us (4.8 / 6.4 / 6.8 TB/s: ~6.4 is what HBM reads deliver).  WM_XATTN_WGS: workgroup cap (A/B).
         static const int env_cap = getenv("WM_XATTN_WGS") ? atoi(getenv("WM_XATTN_WGS")) : 0;
         const int cap = env_cap > 0 ? env_cap : 256;
         int n_wg = B * H;
