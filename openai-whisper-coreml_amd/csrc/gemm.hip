@@ -247,17 +247,27 @@ __device__ __forceinline__ void resid_tile_staged(const GemmDev &p, const f32x4 
                 for (int r = 0; r < 4; ++r)
                     *(float *)(L + (ii * 16 + fq * 4 + r) * STAGE_F32_ROW_BYTES + (j * 16 + frow) * 4) =
                         acc[ps * 2 + ii][j][r] + bv[j];
+        // the read-modify-write is load LATENCY: all eight rows of the pass are requested before the first one is added
+        // and stored (one HBM round trip per pass instead of eight load -> add -> store chains; the compiler cannot hoist
+        // the loads over the stores itself: they may alias).  Rows past M re-read row M - 1 and store nothing.
+        float4 *dst[8];
+        float4 c[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const unsigned m = (unsigned)(mwave0 + ps * 32 + t * 4 + rrow);
+            const unsigned mc = (int)m < p.M ? m : (unsigned)(p.M - 1);
+            const unsigned q = mc / rpb, rem = mc - q * rpb;
+            dst[t] = (float4 *)((float *)p.C + (long)q * p.c_bstride + (long)rem * p.c_rstride + nwave0 + c4 * 4);
+            c[t] = *dst[t];
+        }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int row = t * 4 + rrow;
             const float4 v = *(const float4 *)(L + row * STAGE_F32_ROW_BYTES + c4 * 16);
-            const unsigned m = (unsigned)(mwave0 + ps * 32 + row);
-            if ((int)m >= p.M) continue;
-            const unsigned q = m / rpb, rem = m - q * rpb;
-            float4 *dst = (float4 *)((float *)p.C + (long)q * p.c_bstride + (long)rem * p.c_rstride + nwave0 + c4 * 4);
-            float4 c = *dst;
-            c.x += v.x; c.y += v.y; c.z += v.z; c.w += v.w;
-            *dst = c;
+            if (mwave0 + ps * 32 + row >= p.M) continue;
+            float4 r = c[t];
+            r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+            *dst[t] = r;
         }
     }
 }
