@@ -202,21 +202,23 @@ __device__ __forceinline__ void store_tile_staged(const GemmDev &p, const f32x4 
                     if (EPI == EPI_GELU_BF16) v = gelu_erf(v);
                     *(bf16_t *)(L + (ii * 16 + fq * 4 + r) * STAGE_ROW_BYTES + (j * 16 + frow) * 2) = f2bf(v);
                 }
+        // row -> (batch, row-in-batch): ONE division per pass (the lane's first row), then 8 rows further per step
+        // (16 divisions per lane per tile were ~1 us of the epilogue; rows-per-batch >= 8 is checked by the caller)
+        const unsigned div = EPI == EPI_XKV ? seq : rpb;
+        unsigned m = (unsigned)(mwave0 + ps * 64 + rrow);
+        unsigned q = m / div, rem = m - q * div;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int row = t * 8 + rrow;
             const uint4 val = *(const uint4 *)(L + row * STAGE_ROW_BYTES + chunk * 16);
-            const unsigned m = (unsigned)(mwave0 + ps * 64 + row);
-            if ((int)m >= p.M) continue;
-            long roff;
-            if (EPI == EPI_XKV) {
-                const unsigned b = m / seq, sq = m - b * seq;
-                roff = ((long)b * p.n_head * p.seq + sq) * 64;
-            } else {
-                const unsigned q = m / rpb, rem = m - q * rpb;
-                roff = (long)q * p.c_bstride + (long)rem * p.c_rstride;
+            if ((int)m < p.M) {
+                const long roff = EPI == EPI_XKV ? ((long)q * p.n_head * p.seq + rem) * 64
+                                                 : (long)q * p.c_bstride + (long)rem * p.c_rstride;
+                *(uint4 *)((bf16_t *)p.C + roff + coff + chunk * 8) = val;
             }
-            *(uint4 *)((bf16_t *)p.C + roff + coff + chunk * 8) = val;
+            m += 8;
+            rem += 8;
+            if (rem >= div) { rem -= div; ++q; }
         }
     }
 }
@@ -236,6 +238,7 @@ __device__ __forceinline__ void resid_tile_staged(const GemmDev &p, const f32x4 
 #pragma unroll
     for (int j = 0; j < NJ; ++j) bv[j] = p.bias ? p.bias[nwave0 + j * 16 + frow] : 0.f;
     const unsigned rpb = (unsigned)p.c_rpb;
+    const unsigned q_last = (unsigned)(p.M - 1) / rpb, rem_last = (unsigned)(p.M - 1) - q_last * rpb;  // (uniform)
     const int rrow = lane >> 4, c4 = lane & 15;
 #pragma unroll
     for (int ps = 0; ps < MI / 2; ++ps) {
@@ -252,13 +255,19 @@ __device__ __forceinline__ void resid_tile_staged(const GemmDev &p, const f32x4 
         // the loads over the stores itself: they may alias).  Rows past M re-read row M - 1 and store nothing.
         float4 *dst[8];
         float4 c[8];
+        // row -> (batch, row-in-batch): one division per pass, then 4 rows further per step (rows-per-batch >= 8); rows
+        // past M re-read row M - 1 (selects, no branches: the eight loads must stay one batch)
+        unsigned m = (unsigned)(mwave0 + ps * 32 + rrow);
+        unsigned q = m / rpb, rem = m - q * rpb;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const unsigned m = (unsigned)(mwave0 + ps * 32 + t * 4 + rrow);
-            const unsigned mc = (int)m < p.M ? m : (unsigned)(p.M - 1);
-            const unsigned q = mc / rpb, rem = mc - q * rpb;
-            dst[t] = (float4 *)((float *)p.C + (long)q * p.c_bstride + (long)rem * p.c_rstride + nwave0 + c4 * 4);
+            const bool ok = (int)m < p.M;
+            const unsigned mq = ok ? q : q_last, mr = ok ? rem : rem_last;
+            dst[t] = (float4 *)((float *)p.C + (long)mq * p.c_bstride + (long)mr * p.c_rstride + nwave0 + c4 * 4);
             c[t] = *dst[t];
+            m += 4;
+            rem += 4;
+            if (rem >= rpb) { rem -= rpb; ++q; }
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -375,13 +384,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
         // bf16 outputs leave through LDS (the loop's last __syncthreads() means nobody reads the operand tiles any more);
         // the V^T third of the QKV projection keeps its transposed register path
         const int nwave0 = n0 + wc * 64;
-        if (p.N % 64 == 0 && !(EPI == EPI_QKV_ENC && nwave0 >= 2 * p.d_model)) {  // wave-uniform
+        if (p.N % 64 == 0 && (EPI == EPI_XKV ? p.seq : p.c_rpb) >= 8 &&
+            !(EPI == EPI_QKV_ENC && nwave0 >= 2 * p.d_model)) {  // wave-uniform
             store_tile_staged<EPI, 4, 4>(p, acc, m0 + wr * 64, nwave0, &lds[0][0][0] + wave * STAGE_WAVE_BYTES, lane);
             return;
         }
     }
     if constexpr (EPI == EPI_RESID_F32) {
-        if (p.N % 64 == 0) {
+        if (p.N % 64 == 0 && p.c_rpb >= 8) {
             resid_tile_staged<4, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, &lds[0][0][0] + wave * STAGE_WAVE_BYTES, lane);
             return;
         }
@@ -567,13 +577,14 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
     if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV_ENC || EPI == EPI_XKV) {
         // bf16 outputs leave through LDS: after the barrier above every wave has finished reading the operand tiles
         const int nwave0 = n0 + wc * 64;
-        if (p.N % 64 == 0 && !(EPI == EPI_QKV_ENC && nwave0 >= 2 * p.d_model)) {  // wave-uniform
+        if (p.N % 64 == 0 && (EPI == EPI_XKV ? p.seq : p.c_rpb) >= 8 &&
+            !(EPI == EPI_QKV_ENC && nwave0 >= 2 * p.d_model)) {  // wave-uniform
             store_tile_staged<EPI, 8, 4>(p, acc, m0 + wr * 128, nwave0, lds + wave * STAGE_WAVE_BYTES, lane);
             return;
         }
     }
     if constexpr (EPI == EPI_RESID_F32) {
-        if (p.N % 64 == 0) {
+        if (p.N % 64 == 0 && p.c_rpb >= 8) {
             resid_tile_staged<8, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, lds + wave * STAGE_WAVE_BYTES, lane);
             return;
         }
