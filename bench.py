@@ -176,6 +176,10 @@ def main():
                          "process at the timed group size)")
     args = ap.parse_args()
 
+    # One hardware queue per HIP stream (the runtime's default of 4 makes the fifth stream of the process share a queue
+    # with an earlier one -- under torch.distributed the null stream and RCCL's streams come first, and two decode lanes
+    # on one queue would run one after the other).  Must be in the environment before the HIP runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
