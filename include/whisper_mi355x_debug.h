@@ -37,6 +37,11 @@ WM_API int wmdbg_enc_attention(wm_ctx *ctx, const float *q, const float *k, cons
 /* Decode-step skinny GEMM: out[B][N] = (ln_g ? LayerNorm(x) : x) . W[N][K]^T + bias; B <= 16. */
 WM_API int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, const float *ln_b, const float *W,
                    const float *bias, float *out, int B, int N, int K);
+/* The decoder's residual product (out-projection / fc2): resid[B][N] += x[B][K] . W[N][K]^T + bias, any B <= 128.
+ * Also returns the bf16 copy of the updated residual (widened to f32) and its per-row (sum, sum of squares) rebuilt from
+ * the per-tile LayerNorm partials the kernel leaves for the next folded GEMV: stats [B][2]. */
+WM_API int wmdbg_dec_gemv_resid(wm_ctx *ctx, const float *x, const float *W, const float *bias, float *resid, float *copy_bf16,
+                         float *stats, int B, int N, int K);
 /* Single-query attention over a cache: q [B][H*64], k/v [B][H][T][64], keys 0..n_keys-1;
  * out = the bf16 head outputs widened to f32.  nsplit in 1..8. */
 WM_API int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, const float *v, int B, int H, int T,

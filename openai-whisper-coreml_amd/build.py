@@ -74,7 +74,7 @@ def build(force=False, verbose=True):
     for lib, members, vmap in ((LIB, prod, maps["product"]), (DBG_LIB, objs, maps["debug"])):
         if changed or not os.path.exists(lib):
             cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + members + [
-                "-Wl,-rpath,/opt/rocm/lib", "-Wl,--version-script=" + vmap, "-L/opt/rocm/lib", "-lrccl", "-lpthread"]
+                "-Wl,-rpath,/opt/rocm/lib", "-Wl,--version-script=" + vmap, "-lpthread", "-ldl"]   # RCCL: dlopen'ed by wm_multi_create, never linked
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

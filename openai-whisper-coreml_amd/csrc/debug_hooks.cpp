@@ -209,6 +209,64 @@ extern "C" int wmdbg_dec_gemv(wm_ctx *ctx, const float *x, const float *ln_g, co
     return rc;
 }
 
+// The residual product of a decoder layer (DE_RESID: attention out-projection K = d, fc2 K = 4d) at any decode-group size:
+// this is the epilogue the two-parts-per-wave kernel serves above 16 rows when K splits over 16 waves (d = 768 / 1024 / 1280).
+extern "C" int wmdbg_dec_gemv_resid(wm_ctx *ctx, const float *x, const float *W, const float *bias, float *resid,
+                                    float *copy_bf16, float *stats, int B, int N, int K) {
+    WM_TRY(wm_ctx_make_current(ctx));
+    WM_REQUIRE(B >= 1 && B <= WM_DEC_MAXB && N % 16 == 0, WM_ERR_INVALID, "wmdbg_dec_gemv_resid: B out of range / N % 16");
+    const int Bpad = ((B + 15) / 16) * 16;
+    std::vector<bf16_t> w16, x16;
+    {
+        std::vector<float> wp((size_t)N * K, 0.f), xp((size_t)Bpad * K, 0.f);
+        for (size_t r = 0; r < (size_t)N; ++r)
+            for (size_t k = 0; k < (size_t)K; ++k) wp[wm_tiled_offset(r, k, (size_t)K)] = W[r * K + k];
+        for (size_t b = 0; b < (size_t)B; ++b)
+            for (size_t k = 0; k < (size_t)K; ++k) xp[wm_tiled_offset(b, k, (size_t)K)] = x[b * K + k];
+        to_bf16(wp.data(), w16, wp.size());
+        to_bf16(xp.data(), x16, xp.size());
+    }
+    void *dx16, *dW, *dbias = nullptr, *dres, *dcopy, *dst;
+    hipStream_t s = ctx->stream;
+    WM_TRY(up(&dx16, x16.data(), x16.size() * 2, s));
+    WM_TRY(up(&dW, w16.data(), w16.size() * 2, s));
+    WM_TRY(up(&dres, resid, (size_t)B * N * 4, s));
+    WM_TRY(up(&dcopy, nullptr, (size_t)Bpad * N * 2, s));
+    WM_TRY(up(&dst, nullptr, (size_t)(Bpad / 16) * 2 * N * 4, s));
+    if (bias) WM_TRY(up(&dbias, bias, (size_t)N * 4, s));
+    DecGemvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.epi = DE_RESID; a.B = B; a.N = N; a.K = K; a.W = (const bf16_t *)dW; a.c2 = (const float *)dbias;
+    a.a = (const bf16_t *)dx16; a.out_f32 = (float *)dres; a.out_bf16 = (bf16_t *)dcopy; a.ldo = N;
+    a.stats_out = (float *)dst;
+    int rc = wm_dec_gemv(ctx, a);
+    if (rc == WM_OK) {
+        std::vector<bf16_t> c16((size_t)Bpad * N), lin((size_t)B * N);
+        std::vector<float> st((size_t)(Bpad / 16) * 2 * N);
+        WM_HIP(hipMemcpyAsync(resid, dres, (size_t)B * N * 4, hipMemcpyDeviceToHost, s));
+        WM_HIP(hipMemcpyAsync(c16.data(), dcopy, c16.size() * 2, hipMemcpyDeviceToHost, s));
+        WM_HIP(hipMemcpyAsync(st.data(), dst, st.size() * 4, hipMemcpyDeviceToHost, s));
+        WM_HIP(hipStreamSynchronize(s));
+        for (size_t b = 0; b < (size_t)B; ++b)
+            for (size_t n = 0; n < (size_t)N; ++n) lin[b * N + n] = c16[wm_tiled_offset(b, n, (size_t)N)];
+        from_bf16(lin, copy_bf16);
+        for (int b = 0; b < B; ++b) {   // block (b / 16): [N/16 parts][16][2]
+            const float *blk = st.data() + (size_t)(b >> 4) * 2 * N;
+            float s1 = 0.f, s2 = 0.f;
+            for (int part = 0; part < N / 16; ++part) {
+                s1 += blk[(part * 16 + (b & 15)) * 2];
+                s2 += blk[(part * 16 + (b & 15)) * 2 + 1];
+            }
+            stats[b * 2] = s1;
+            stats[b * 2 + 1] = s2;
+        }
+    }
+    void *fr[] = {dx16, dW, dbias, dres, dcopy, dst};
+    for (void *p : fr)
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
 // Single-query attention: q f32 [B][H*64], k/v f32 [B][H][T][64] (rounded to bf16), first
 // n_keys positions; `nsplit` (1, 2, 4, 8) workgroups share the 8 streams of a pair; out f32 [B][H*64].
 extern "C" int wmdbg_dec_attention(wm_ctx *ctx, const float *q, const float *k, const float *v, int B, int H, int T,

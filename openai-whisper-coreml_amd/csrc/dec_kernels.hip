@@ -963,13 +963,15 @@ static bool pf_enabled(int B) {
     return !no_pf && B <= max_b;
 }
 
-static void pick_shape(int epi, bool ln, int spw, int B, int n_tiles, int *tn, int *nblk) {
+static void pick_shape(int epi, bool ln, int spw, int nw, int B, int n_tiles, int *tn, int *nblk) {
     static const int env_tn = getenv("WM_GEMV_TN") ? atoi(getenv("WM_GEMV_TN")) : 0;
     static const int env_nb = getenv("WM_GEMV_NBLK") ? atoi(getenv("WM_GEMV_NBLK")) : 0;
     const int blocks = (B + 15) / 16;
     *tn = 1;
     *nblk = 1;
-    if (blocks < 2 || spw > 8) return;  // one block, or the 16-wave K = 4d products (register budget): one unit
+    // one block, or a 16-wave K split (K = 4d at d >= 768: the multi-unit kernels are built for <= 8 waves -- launch
+    // bounds 512, register budget): one unit per workgroup, more workgroups along the batch
+    if (blocks < 2 || nw > 8) return;
     *nblk = env_nb == 1 ? 1 : 2;
     const bool wide = ln && (epi == DE_QKV || epi == DE_GELU || epi == DE_LOGITS) && *nblk == 2 && spw <= 6;
     if (!wide) return;
@@ -1014,11 +1016,14 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     p.ts = a.ts;
     p.n_tiles = (a.N + 15) / 16;
     int tn = 1, nblk = 1;
-    pick_shape(a.epi, ln, spw, a.B, p.n_tiles, &tn, &nblk);
+    pick_shape(a.epi, ln, spw, nw, a.B, p.n_tiles, &tn, &nblk);
     p.bgroups = ((a.B + 15) / 16 + nblk - 1) / nblk;
-    // the 16-part K = 4d residual product at more than one batch block: two parts per wave, 8-wave workgroups (two per CU)
+    // the 16-part K = 4d residual product at more than one batch block: two parts per wave, 8-wave workgroups (two per
+    // CU).  pick_shape keeps every 16-wave split at one (tile, block) unit per workgroup, which is what the two-part
+    // kernel is built for (d = 768 / 1024 / 1280: spw = 6 / 8 / 10).
     static const bool no_ppw = getenv("WM_GEMV_NO_PPW2") != nullptr;
-    const int ppw = (!no_ppw && !ln && a.epi == DE_RESID && nw == 16 && a.B > 16 && spw >= 6 && spw <= 10) ? 2 : 1;
+    const int ppw = (!no_ppw && !ln && a.epi == DE_RESID && nw == 16 && a.B > 16 && spw >= 6 && spw <= 10 && tn == 1 &&
+                     nblk == 1) ? 2 : 1;
     p.n_tg = (p.n_tiles + tn - 1) / tn;
     p.n_tg_pad = p.bgroups > 1 ? (p.n_tg + 7) / 8 * 8 : p.n_tg;  // (tile group, batch group) decode needs rows of 8
     int grid = p.n_tg_pad * p.bgroups;

@@ -22,6 +22,7 @@ struct wm_vocab {
 };
 
 namespace {
+constexpr long kMaxVocabId = 1L << 20;
 // GPT-2 bytes_to_unicode(), inverted: code point -> byte
 void byte_alphabet(std::unordered_map<uint32_t, unsigned char> &inv) {
     bool nice[256] = {false};
@@ -91,7 +92,15 @@ bool read_json_string(const std::string &s, size_t &i, std::vector<uint32_t> &cp
         else if ((c >> 3) == 30) { v = c & 0x07; len = 4; }
         else return false;
         if (i + len > s.size()) return false;
-        for (int k = 1; k < len; ++k) v = (v << 6) | ((unsigned char)s[i + k] & 0x3f);
+        for (int k = 1; k < len; ++k) {
+            const unsigned char cc = (unsigned char)s[i + k];
+            if ((cc & 0xC0) != 0x80) return false;   // not a continuation byte (10xxxxxx): malformed UTF-8 is rejected
+            v = (v << 6) | (cc & 0x3f);
+        }
+        // overlong encodings and surrogates are malformed too
+        if ((len == 2 && v < 0x80) || (len == 3 && v < 0x800) || (len == 4 && (v < 0x10000 || v > 0x10FFFF)) ||
+            (v >= 0xD800 && v <= 0xDFFF))
+            return false;
         cps.push_back(v);
         i += len;
     }
@@ -144,7 +153,9 @@ extern "C" int wm_vocab_load(const char *vocab_json_path, wm_vocab **out) try {
             long id = 0;
             size_t digits = 0;
             while (i < s.size() && s[i] >= '0' && s[i] <= '9' && digits < 9) { id = id * 10 + (s[i] - '0'); ++i; ++digits; }
-            if (digits == 0 || id > 10000000) { ok = false; break; }
+            // ids index a dense table: cap them at a realistic vocabulary size (Whisper: 51 866; GPT-class: < 2^20) so that
+            // one bogus id in a malformed file cannot allocate hundreds of megabytes of empty strings
+            if (digits == 0 || id >= kMaxVocabId) { ok = false; break; }
             std::string bytes;
             for (uint32_t cp : cps) {
                 auto it = inv.find(cp);

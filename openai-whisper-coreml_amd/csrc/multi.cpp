@@ -10,14 +10,71 @@
 //     bound; every rank ends with every stream, rank 0's copy is handed to the caller.
 // bench.py --gpus N uses the one-process-per-GPU launch the driver prescribes (torch.distributed over the same RCCL);
 // this is the same partition and the same collective for a dlopen-only host (host/multi_main.cpp).
-#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is NOT a link-time dependency (see rccl_api below)
+#include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "model.h"
+
+// RCCL is bound at run time, on the first wm_multi_create, never at link time:
+//   * a front-end-only or single-GPU host (the reference's app calls generate_spectrogram and one model) must be able to
+//     dlopen libwhisper_mi355x.so on a machine without librccl;
+//   * a process that already carries an RCCL (bench.py --gpus N: torch's bundled librccl.so, same soname) must keep ONE
+//     copy -- a hard DT_NEEDED on /opt/rocm/lib/librccl beside torch's put two builds behind one soname.
+// Resolution order: an RCCL already mapped into the process (RTLD_NOLOAD), $WM_RCCL_PATH, then the usual search
+// (this library's RUNPATH is /opt/rocm/lib).
+namespace {
+struct RcclApi {
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;   // why binding failed (empty when bound)
+    bool ok = false;
+};
+
+const RcclApi &rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        void *h = nullptr;
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (const char *n : names)
+            if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);   // the copy the process already has (torch's, the host's)
+        if (!h)
+            if (const char *e = getenv("WM_RCCL_PATH")) h = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+        for (const char *n : names)
+            if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            const char *e = dlerror();
+            api.err = std::string("librccl.so.1 not found (set WM_RCCL_PATH): ") + (e ? e : "dlopen failed");
+            return;
+        }
+        auto sym = [&](const char *name) -> void * {
+            void *p = dlsym(h, name);
+            if (!p && api.err.empty()) api.err = std::string("librccl: missing symbol ") + name;
+            return p;
+        };
+        api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        api.ok = api.err.empty();
+    });
+    return api;
+}
+}  // namespace
 
 struct wm_multi {
     std::vector<wm_ctx *> ctx;
@@ -42,6 +99,7 @@ extern "C" int wm_multi_pack_tokens(const int32_t *tokens, const int32_t *lens, 
                                     int32_t *payload) try {
     WM_REQUIRE(payload && n_local >= 0 && n_local <= per && max_new >= 0 && (n_local == 0 || (tokens && lens)),
                WM_ERR_INVALID, "pack_tokens: bad arguments");
+    WM_REQUIRE((uint64_t)per * (1 + (uint64_t)max_new) <= (uint64_t)1 << 40, WM_ERR_INVALID, "pack_tokens: payload too large");
     const size_t stride = 1 + (size_t)max_new;
     memset(payload, 0, (size_t)per * stride * sizeof(int32_t));
     for (int i = 0; i < n_local; ++i) {
@@ -53,12 +111,14 @@ extern "C" int wm_multi_pack_tokens(const int32_t *tokens, const int32_t *lens, 
 
 extern "C" int wm_multi_unpack_tokens(const int32_t *gathered, int world_size, int per, int max_new, int n_chunks,
                                       int32_t *tokens_out, int32_t *lens_out) try {
-    WM_REQUIRE(gathered && tokens_out && lens_out && world_size >= 1 && per >= 0 && n_chunks >= 0 &&
+    WM_REQUIRE(gathered && tokens_out && lens_out && world_size >= 1 && per >= 0 && n_chunks >= 0 && max_new >= 0 &&
                    (long)n_chunks <= (long)world_size * per, WM_ERR_INVALID, "unpack_tokens: bad arguments");
+    WM_REQUIRE((uint64_t)world_size * (uint64_t)per * (1 + (uint64_t)max_new) <= (uint64_t)1 << 40, WM_ERR_INVALID,
+               "unpack_tokens: payload too large");
     const size_t stride = 1 + (size_t)max_new;
-    for (int c = 0; c < n_chunks; ++c) {  // rank r's block starts at row r * per of the gathered buffer == chunk r * per
+    for (size_t c = 0; c < (size_t)n_chunks; ++c) {  // rank r's block starts at row r * per of the gathered buffer == chunk r * per
         lens_out[c] = gathered[c * stride];
-        memcpy(tokens_out + (size_t)c * max_new, gathered + c * stride + 1, (size_t)max_new * sizeof(int32_t));
+        memcpy(tokens_out + c * (size_t)max_new, gathered + c * stride + 1, (size_t)max_new * sizeof(int32_t));
     }
     return WM_OK;
 } WM_API_CATCH
@@ -68,6 +128,8 @@ extern "C" int wm_multi_create(const wm_dims *dims, const int *devices, int n, w
     *out = nullptr;
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < i; ++j) WM_REQUIRE(devices[i] != devices[j], WM_ERR_INVALID, "multi_create: device %d listed twice", devices[i]);
+    const RcclApi &nc = rccl_api();
+    WM_REQUIRE(nc.ok, WM_ERR_STATE, "multi_create: RCCL is not available: %s", nc.err.c_str());
     wm_multi *m = new wm_multi();
     m->dev.assign(devices, devices + n);
     int st = WM_OK;
@@ -78,9 +140,9 @@ extern "C" int wm_multi_create(const wm_dims *dims, const int *devices, int n, w
     }
     if (st == WM_OK) {
         m->comm.resize(n);
-        const ncclResult_t r = ncclCommInitAll(m->comm.data(), n, m->dev.data());
+        const ncclResult_t r = nc.CommInitAll(m->comm.data(), n, m->dev.data());
         if (r != ncclSuccess) {
-            wm_set_error("ncclCommInitAll over %d device(s) failed: %s", n, ncclGetErrorString(r));
+            wm_set_error("ncclCommInitAll over %d device(s) failed: %s", n, nc.GetErrorString(r));
             m->comm.clear();
             st = WM_ERR_HIP;
         }
@@ -104,7 +166,8 @@ extern "C" void wm_multi_destroy(wm_multi *m) {
         if (i < m->d_send.size() && m->d_send[i]) (void)hipFree(m->d_send[i]);
         if (i < m->d_recv.size() && m->d_recv[i]) (void)hipFree(m->d_recv[i]);
     }
-    for (ncclComm_t c : m->comm) (void)ncclCommDestroy(c);
+    if (!m->comm.empty() && rccl_api().ok)
+        for (ncclComm_t c : m->comm) (void)rccl_api().CommDestroy(c);
     for (wm_ctx *c : m->ctx) wm_destroy(c);
     delete m;
 }
@@ -139,6 +202,14 @@ extern "C" int wm_multi_transcribe_greedy(wm_multi *m, const void *pcm, wm_dtype
                "multi_transcribe_greedy: bad arguments");
     WM_REQUIRE(pcm_dtype == WM_I16 || pcm_dtype == WM_F32 || pcm_dtype == WM_F64, WM_ERR_INVALID, "bad pcm dtype");
     const int R = (int)m->ctx.size();
+    WM_REQUIRE(R >= 1 && m->ctx[0]->model, WM_ERR_STATE, "multi_transcribe_greedy: no model");
+    {   // every size that feeds an allocation below is checked against the model BEFORE any thread exists
+        const wm_dims &D = m->ctx[0]->model->dims;
+        WM_REQUIRE(n_prompt >= 1 && n_prompt + max_new <= D.n_text_ctx, WM_ERR_INVALID,
+                   "prompt (%d) + new tokens (%d) must fit the %d-token context", n_prompt, max_new, D.n_text_ctx);
+    }
+    const RcclApi &nc = rccl_api();
+    WM_REQUIRE(nc.ok, WM_ERR_STATE, "RCCL is not available: %s", nc.err.c_str());
     const int per = (B + R - 1) / R;
     const size_t stride = 1 + (size_t)max_new;
     const size_t elem = pcm_dtype == WM_I16 ? 2 : pcm_dtype == WM_F32 ? 4 : 8;
@@ -148,8 +219,19 @@ extern "C" int wm_multi_transcribe_greedy(wm_multi *m, const void *pcm, wm_dtype
     std::vector<std::string> errs(R);
     std::vector<std::vector<int32_t>> payload(R, std::vector<int32_t>((size_t)per * stride, 0));
     std::vector<std::thread> th;
+    th.reserve(R);
+    // A worker's body never lets an exception escape (it would std::terminate the host process, not return through the
+    // FFI); if a std::thread cannot be started, the ones already running are joined before the error is reported.
+    struct Joiner {
+        std::vector<std::thread> &t;
+        ~Joiner() {
+            for (auto &x : t)
+                if (x.joinable()) x.join();
+        }
+    } joiner{th};
     for (int r = 0; r < R; ++r) {
         th.emplace_back([&, r] {
+          try {
             int lo = 0, hi = 0;
             (void)wm_multi_partition(B, R, r, &lo, &hi);
             const int n_local = hi - lo;
@@ -170,6 +252,13 @@ extern "C" int wm_multi_transcribe_greedy(wm_multi *m, const void *pcm, wm_dtype
             }
             status[r] = st;
             if (st != WM_OK) errs[r] = wm_last_error();  // thread-local: hand it to the caller's thread
+          } catch (const std::bad_alloc &) {
+            status[r] = WM_ERR_NOMEM;
+            try { errs[r] = "out of host memory"; } catch (...) {}
+          } catch (...) {
+            status[r] = WM_ERR_NOMEM;
+            try { errs[r] = "internal error in the worker thread"; } catch (...) {}
+          }
         });
     }
     for (auto &t : th) t.join();
@@ -179,12 +268,12 @@ extern "C" int wm_multi_transcribe_greedy(wm_multi *m, const void *pcm, wm_dtype
             return status[r];
         }
     // ---- the one collective of the job: fixed-stride all-gather of the token streams (RCCL over xGMI)
-    ncclResult_t nr = ncclGroupStart();
+    ncclResult_t nr = nc.GroupStart();
     for (int r = 0; r < R && nr == ncclSuccess; ++r)
-        nr = ncclAllGather(m->d_send[r], m->d_recv[r], (size_t)per * stride, ncclInt32, m->comm[r], m->ctx[r]->stream);
-    if (nr == ncclSuccess) nr = ncclGroupEnd();
-    else (void)ncclGroupEnd();
-    WM_REQUIRE(nr == ncclSuccess, WM_ERR_HIP, "ncclAllGather failed: %s", ncclGetErrorString(nr));
+        nr = nc.AllGather(m->d_send[r], m->d_recv[r], (size_t)per * stride, ncclInt32, m->comm[r], m->ctx[r]->stream);
+    if (nr == ncclSuccess) nr = nc.GroupEnd();
+    else (void)nc.GroupEnd();
+    WM_REQUIRE(nr == ncclSuccess, WM_ERR_HIP, "ncclAllGather failed: %s", nc.GetErrorString(nr));
     std::vector<int32_t> all((size_t)R * per * stride);
     WM_HIP(hipSetDevice(m->dev[0]));
     WM_HIP(hipMemcpyAsync(all.data(), m->d_recv[0], all.size() * sizeof(int32_t), hipMemcpyDeviceToHost, m->ctx[0]->stream));

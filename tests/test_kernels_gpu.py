@@ -33,6 +33,7 @@ def ctx(pkg):
     lib.wmdbg_enc_attention.argtypes = [vp, vp, vp, vp, ip, ip, ip, vp]
     lib.wmdbg_dec_gemv.argtypes = [vp, vp, vp, vp, vp, vp, vp, ip, ip, ip]
     lib.wmdbg_dec_attention.argtypes = [vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
+    lib.wmdbg_dec_gemv_resid.argtypes = [vp, vp, vp, vp, vp, vp, vp, ip, ip, ip]
     yield c
     c.close()
 
@@ -151,6 +152,36 @@ def test_decode_gemv(ctx, B, N, K, ln):
     # LN path: our bf16 rounding of LN(x) can differ from the kernel's by one ulp on a few elements
     tol = (4e-3 if ln else 2e-4) * np.abs(ref).max()
     assert np.abs(out - ref).max() <= tol, (np.abs(out - ref).max(), np.abs(ref).max())
+
+
+@pytest.mark.parametrize("B,N,K", [(8, 768, 3072), (17, 768, 3072), (32, 768, 3072), (17, 1024, 4096), (32, 1024, 4096),
+                                   (56, 1280, 5120), (17, 768, 768), (40, 1024, 1024), (33, 512, 2048), (128, 384, 1536)])
+def test_decode_gemv_residual_at_every_width_and_group_size(ctx, B, N, K):
+    """the fc2 product (K = 4d) splits K over 16 waves at d = 768 / 1024 / 1280; above one batch block
+    the two-parts-per-wave kernel serves it.  At d = 768 / 1024 the launch-shape choice used to contradict it
+    (WM_ERR_INVALID on every decode step of whisper-small / -medium with more than 16 rows).  Residual update, its bf16
+    copy and the LayerNorm partials, at every model width, one block and several."""
+    rng = np.random.default_rng(B + N + K)
+    x = bf(rng.standard_normal((B, K)) * 0.5 + np.linspace(-0.2, 0.2, K)[None, :])
+    Wt = bf(rng.standard_normal((N, K)) * 0.05 + np.linspace(-0.02, 0.02, N)[:, None])
+    bias = rng.standard_normal(N).astype(np.float32)
+    r0 = rng.standard_normal((B, N)).astype(np.float32)
+    res = r0.copy()
+    cp = np.zeros((B, N), np.float32)
+    stt = np.zeros((B, 2), np.float32)
+    st = ctx.lib.wmdbg_dec_gemv_resid(ctx.handle, P(x), P(Wt), P(bias), P(res), P(cp), P(stt), B, N, K)
+    assert st == 0, ctx.lib.wm_last_error()
+    ref = r0.astype(np.float64) + x.astype(np.float64) @ Wt.astype(np.float64).T + bias
+    scale = np.abs(ref).max()
+    assert np.abs(res - ref).max() <= 2e-4 * scale, (np.abs(res - ref).max(), scale)
+    assert np.abs(cp - res).max() <= 2 ** -8 * scale                        # the bf16 copy of the same rows
+    assert np.allclose(stt[:, 0], res.sum(axis=1), rtol=1e-4, atol=1e-3 * scale)
+    assert np.allclose(stt[:, 1], (res.astype(np.float64) ** 2).sum(axis=1), rtol=1e-4)
+    # bit-level batch invariance of the residual product: row 0 alone == row 0 inside the group
+    one = r0[:1].copy()
+    assert ctx.lib.wmdbg_dec_gemv_resid(ctx.handle, P(x[:1].copy()), P(Wt), P(bias), P(one), P(cp[:1].copy()),
+                                        P(stt[:1].copy()), 1, N, K) == 0
+    assert np.array_equal(one[0], res[0])
 
 
 @pytest.mark.parametrize("B,H,T,n_keys,nsplit", [(2, 2, 448, 1, 1), (2, 2, 448, 37, 1), (1, 3, 448, 448, 1),

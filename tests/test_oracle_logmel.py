@@ -131,3 +131,28 @@ def test_kat5_f64_restatement_vs_openai_whisper_f32_formulation(oracle_lib, m80)
         assert got.shape == (80, 3000)
         err = np.abs(got - want).max()
         assert err <= 1e-5, err
+
+
+@pytest.mark.parametrize("n_mels,gate", [(80, 1e-5), (128, 5e-5)])
+def test_kat7_oracle_vs_transformers_feature_extractor(oracle_lib, m80, n_mels, gate):
+    """VERDICT r2 #7b: a THIRD, independent formulation -- transformers.WhisperFeatureExtractor (numpy: its own slaney
+    filterbank generator, its own framing / reflect padding / window, power spectrum, log10, max - 8 clamp, (x + 4) / 4),
+    at 80 mel bins (the reference's m80.npy: its generated filters agree to 2e-9) and at 128 (large-v3; no reference
+    artefact exists for it).  Measured: 3.4e-6 / 1.5e-5 max-abs on these chunks (a handful of low-energy cells carry the
+    128-bin maximum); an index, frame-count, padding or clamp disagreement shows up as >= 1e-2."""
+    tr = pytest.importorskip("transformers")
+    fe = tr.WhisperFeatureExtractor(feature_size=n_mels)
+    filt = np.ascontiguousarray(fe.mel_filters.T, dtype=np.float32)
+    assert filt.shape == (n_mels, 201)
+    if n_mels == 80:
+        assert np.abs(filt - m80).max() <= 2e-8          # HF regenerates what export_m80.py:4-5 exported
+    for seed in (0, 7):
+        x = L.synth_chunk(seed)
+        got = fe(x, sampling_rate=16000, return_tensors="np")["input_features"][0].astype(np.float64)
+        assert got.shape == (n_mels, 3000)
+        want = L.log_mel(x, m80 if n_mels == 80 else filt)
+        if n_mels == 80:
+            c, _ = oracle_logmel(oracle_lib, x)
+            assert np.abs(c - want).max() <= 1e-12       # the C restatement is the same numbers
+        err = np.abs(got - want).max()
+        assert err <= gate, err
