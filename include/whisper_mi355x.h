@@ -150,7 +150,10 @@ WM_API int wm_detect_language_probs(wm_ctx *ctx, const float *xa, int B, int32_t
  *   pcm        : [B][480000], dtype WM_I16 / WM_F32 / WM_F64, mem-space selectable;
  *   prompt     : i32 [n_prompt] initial tokens (e.g. {sot, lang, transcribe, notimestamps});
  *   max_new    : tokens to generate per chunk (<= n_text_ctx - n_prompt);
- *   eot        : stop token; pass -1 to suppress stopping (fixed-length benchmark decode);
+ *   eot        : stop token; pass -1 to suppress stopping (fixed-length benchmark decode).  With eot >= 0 a chunk that
+ *                has produced it leaves the decode (its K/V caches are not read again) and a decode group whose chunks
+ *                have all stopped is not decoded any further: the work follows the longest live sequence, the results
+ *                are what decoding all max_new positions and truncating would give;
  *   tokens_out : i32 [B][max_new] (host), padded with `eot` after a chunk stops;
  *   lens_out   : i32 [B] (host) generated length per chunk. */
 WM_API int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int B,
@@ -174,6 +177,13 @@ WM_API int wm_set_suppress(wm_ctx *ctx, const int32_t *suppress, int n, const in
  * enable = 0 switches the rules off.  Same inheritance as wm_set_suppress. */
 WM_API int wm_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t timestamp_begin, int32_t eot,
                            int32_t max_initial_timestamp_index);
+
+/* Per-chunk token budgets for the NEXT wm_transcribe_greedy call on this context (consumed by it; n must equal that
+ * call's B): chunk i generates at most budgets[i] tokens (clamped to max_new), lens_out[i] <=
+ * budgets[i].  A chunk that has reached its budget -- like one that has emitted `eot` -- LEAVES the decode: its caches are
+ * not read again, and once every chunk of a decode group is finished no further position is launched for the group
+ * (serving: per-request max_tokens; bench.py: a synthetic early-stop workload).  n = 0 clears. */
+WM_API int wm_set_token_budgets(wm_ctx *ctx, const int32_t *budgets, int n);
 
 /* ------------------------------------------------- all GPUs of the node, one host process --- */
 /* the Swift host dlopens ONE library in ONE process; wm_multi drives n GPUs from it.  Weights are

@@ -108,6 +108,7 @@ def load_library(path=None):
         "wm_decode_logits": [vp, vp, ip, ip, vp, vp, ip],
         "wm_detect_language": [vp, vp, ip, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, ip],
         "wm_transcribe_greedy": [vp, vp, ip, ip, vp, ip, ip, ctypes.c_int32, vp, vp, ip],
+        "wm_set_token_budgets": [vp, vp, ip],
         "wm_dev_malloc": [vp, sz, pp],
         "wm_dev_free": [vp, vp],
         "wm_dev_upload": [vp, vp, vp, sz],
@@ -356,9 +357,17 @@ class Context:
                                                     ctypes.c_int32]
         _check(self.lib, self.lib.wm_set_timestamp_rules(self.handle, 1 if enable else 0, timestamp_begin, eot, max_initial))
 
-    def transcribe_greedy(self, pcm, prompt, max_new, eot=-1, mem=WM_MEM_HOST, pcm_dtype=None, B=None):
+    def set_token_budgets(self, budgets):
+        """Per-chunk token budgets of the NEXT transcribe_greedy call (len == its B; consumed by it)."""
+        a = np.ascontiguousarray(list(budgets), dtype=np.int32)
+        _check(self.lib, self.lib.wm_set_token_budgets(self.handle, _ptr(a) if a.size else None, int(a.size)))
+
+    def transcribe_greedy(self, pcm, prompt, max_new, eot=-1, mem=WM_MEM_HOST, pcm_dtype=None, B=None, budgets=None):
         """pcm: host array [B][480000] (int16/float32/float64), or a device pointer
-        (c_void_p) with pcm_dtype and B given when mem == WM_MEM_DEVICE."""
+        (c_void_p) with pcm_dtype and B given when mem == WM_MEM_DEVICE.  budgets: per-chunk token budgets
+        (wm_set_token_budgets) for this call."""
+        if budgets is not None:
+            self.set_token_budgets(budgets)
         prompt = np.ascontiguousarray(prompt, dtype=np.int32)
         if mem == WM_MEM_HOST:
             pcm = np.ascontiguousarray(pcm)

@@ -569,11 +569,18 @@ __global__ __launch_bounds__(NS * 64) void dec_rows_attn_kernel(const float *__r
                                                                 const int *__restrict__ pos_ptr,
                                                                 bf16_t *__restrict__ att, float *__restrict__ part,
                                                                 int nsplit, int n_bh, int n_wg,
-                                                                const char *pf_ptr, long pf_tile_bytes, int flat_wpw) {
+                                                                const char *pf_ptr, long pf_tile_bytes, int flat_wpw,
+                                                                const int *__restrict__ live_rows,
+                                                                const int *__restrict__ n_live_ptr) {
     if ((int)blockIdx.x >= n_wg) {  // L2 warm-up workgroup for the next GEMV's weights
         l2_warm_tile(pf_ptr, pf_tile_bytes, (int)blockIdx.x - n_wg, blockDim.x);
         return;
     }
+    // Early stop: sequences that have emitted <|endoftext|> (or used up their token budget) leave the decode group.
+    // The arg-max kernel keeps a COMPACT list of the live rows; the pairs walked here are (live row, head), dealt to the
+    // workgroups exactly like the full set, so the cache of a finished sequence is never read again and the remaining
+    // pairs stay balanced over the chip.  (null: every row is live -- the fixed-length benchmark decode.)
+    if (n_live_ptr) n_bh = *n_live_ptr * H;
     __shared__ float wm_[NS], wl_[NS];
     __shared__ float wo_[NS][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -593,9 +600,11 @@ __global__ __launch_bounds__(NS * 64) void dec_rows_attn_kernel(const float *__r
         bh_step = n_bh;  // one pair per wave
     }
     // n_wg <= n_bh workgroups (per split) walk the (sequence, head) pairs
-    for (int bh = bh0; bh < n_bh; bh += bh_step) {
-        if (flat_wpw == 0 && bh != (int)blockIdx.x) __syncthreads();  // the previous pair's merge has been read
-        const int b = bh / H, h = bh % H;
+    for (int pi = bh0; pi < n_bh; pi += bh_step) {
+        if (flat_wpw == 0 && pi != (int)blockIdx.x) __syncthreads();  // the previous pair's merge has been read
+        const int h = pi % H;
+        const int b = live_rows ? live_rows[pi / H] : pi / H;
+        const int bh = b * H + h;
         const bf16_t *kb = kc + (long)bh * T_stride * 64 + e8 * 8;
         const bf16_t *vb = vc + (long)bh * T_stride * 64 + e8 * 8;
         float qe[8];
@@ -724,8 +733,9 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
                                                              float *__restrict__ x, bf16_t *__restrict__ xb,
                                                              float *__restrict__ stats_out, WmTsDev ts,
                                                              int *__restrict__ arrive, int fallback_tok,
-                                                             float *__restrict__ mean_buf) {
+                                                             float *__restrict__ mean_buf, WmStopDev stop) {
     __shared__ int tok_s[16];
+    __shared__ int is_last_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pos = pos_ptr ? *pos_ptr : 0;
     const int bw = blockIdx.x * 16;  // this workgroup's rows: one per wave
@@ -781,7 +791,16 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
         }
         if (lane == 0) {
             // key == 0: nothing admissible (every allowed id suppressed, or NaN logits): never index with -1
-            const int tok = key ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : fallback_tok;
+            int tok = key ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : fallback_tok;
+            if (stop.done && pos + 1 >= n_prompt) {
+                // the token at index pos + 1 is generated token number gi (0-based)
+                const int gi = pos + 1 - n_prompt;
+                if (stop.done[b]) {
+                    tok = stop.pad_tok;                        // finished earlier: padding (the host truncates at the length)
+                } else if ((stop.eot >= 0 && tok == stop.eot) || (stop.budget && gi + 1 >= stop.budget[b])) {
+                    stop.done[b] = 1;                          // this token is the row's last
+                }
+            }
             if (ts.rng && pos + 1 >= n_prompt) {
                 // the token at index pos + 1 was sampled: advance the history and derive the ranges of the next position
                 int *hs = ts.hist + b * 4;
@@ -841,14 +860,56 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
     }
     // *pos_ptr has ONE writer: the last workgroup to arrive (every workgroup read the position before it arrived)
     __syncthreads();
-    if (threadIdx.x == 0 && pos_ptr) {
-        if (gridDim.x == 1) {
-            *pos_ptr = pos + 1;
-        } else if (atomicAdd(arrive, 1) == (int)gridDim.x - 1) {
-            *arrive = 0;
-            *pos_ptr = pos + 1;
+    if (!stop.done) {
+        if (threadIdx.x == 0 && pos_ptr) {
+            if (gridDim.x == 1) {
+                *pos_ptr = pos + 1;
+            } else if (atomicAdd(arrive, 1) == (int)gridDim.x - 1) {
+                *arrive = 0;
+                *pos_ptr = pos + 1;
+            }
+        }
+        return;
+    }
+    // early stop on: the last workgroup to arrive also rebuilds the compact list of live rows from every workgroup's
+    // done flags (release fence before arriving, acquire fence after: the flags were written by other CUs / XCDs)
+    if (threadIdx.x == 0) {
+        int last = 1;
+        if (gridDim.x > 1) {
+            __threadfence();
+            last = atomicAdd(arrive, 1) == (int)gridDim.x - 1;
+            if (last) {
+                *arrive = 0;
+                __threadfence();
+            }
+        }
+        is_last_s = last;
+    }
+    __syncthreads();
+    if (is_last_s && wave == 0) {
+        int n = 0;
+        for (int b0 = 0; b0 < B; b0 += 64) {  // B <= 128: two ballots
+            const int b = b0 + lane;
+            const bool live = b < B && __hip_atomic_load(stop.done + (b < B ? b : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+            const unsigned long long m = __ballot(live);
+            if (live) stop.live_rows[n + __popcll(m & ((1ull << lane) - 1ull))] = b;
+            n += __popcll(m);
+        }
+        if (lane == 0) {
+            *stop.n_live = n;
+            if (pos_ptr) *pos_ptr = pos + 1;
         }
     }
+}
+
+// start of a decode: nobody is done, every row is live
+__global__ void dec_live_init_kernel(WmStopDev stop, int B) {
+    const int b = threadIdx.x;
+    if (b < B) {
+        stop.done[b] = 0;
+        stop.live_rows[b] = b;
+    }
+    if (b == 0) *stop.n_live = B;
 }
 
 // ------------------------------------------------------------------ synthetic weights ----
@@ -1097,7 +1158,7 @@ int wm_dec_attn_splits(int B, int H) {
 
 int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
                      int T_stride, int n_keys, const int *pos_ptr, int nsplit, float *part, bf16_t *att,
-                     bool cross, const bf16_t *pf_ptr, int pf_rows, int pf_k) {
+                     bool cross, const bf16_t *pf_ptr, int pf_rows, int pf_k, const int *live_rows, const int *n_live) {
     WM_REQUIRE(nsplit == 1 || nsplit == 2 || nsplit == 4 || nsplit == 8, WM_ERR_INVALID,
                "dec_attention: nsplit %d is not 1, 2, 4 or 8", nsplit);
     WM_REQUIRE(T_stride <= ATT_MAXK && n_keys <= ATT_MAXK, WM_ERR_INVALID,
@@ -1130,7 +1191,7 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
             wpw = wpw < 1 ? 1 : (wpw > 8 ? 8 : wpw);
             const int g = (units + wpw - 1) / wpw;
             dec_rows_attn_kernel<8, 4, WM_XATTN_NT><<<g, wpw * 64, 0, ctx->stream>>>(
-                q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, 8, B * H, g, nullptr, 0, wpw);
+                q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, 8, B * H, g, nullptr, 0, wpw, live_rows, n_live);
         } else {
             dim3 grid(gx, nsplit);
             // ONE cross-attention workgroup per CU, chip-wide: a workgroup reserves more than half of the CU's 160 KB of
@@ -1149,7 +1210,7 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
             }
             dec_rows_attn_kernel<8, 4, WM_XATTN_NT><<<grid, (8 / nsplit) * 64, nsplit == 1 ? lds_pad : 0, ctx->stream>>>(
                 q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, nsplit, B * H, n_wg, (const char *)pf_ptr,
-                tile_bytes, 0);
+                tile_bytes, 0, live_rows, n_live);
         }
         WM_HIP(hipGetLastError());
     }
@@ -1162,7 +1223,8 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
 }
 
 int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H, int T_stride,
-                          int n_keys, const int *pos_ptr, bf16_t *att, const bf16_t *pf_ptr, int pf_rows, int pf_k) {
+                          int n_keys, const int *pos_ptr, bf16_t *att, const bf16_t *pf_ptr, int pf_rows, int pf_k,
+                          const int *live_rows, const int *n_live) {
     WM_REQUIRE(T_stride <= ATT_MAXK && n_keys <= ATT_MAXK && (pos_ptr || n_keys >= 1), WM_ERR_INVALID,
                "dec_self_attention: 1..%d keys", ATT_MAXK);
     WmProfScope ps(&ctx->prof, "dec_attn_self", ctx->stream);
@@ -1174,7 +1236,8 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
     }
     // a pair is 15-57 KB of cache (<= 448 rows, ~115 on average over a 224-token decode): ONE 4-wave workgroup
     dec_rows_attn_kernel<4, 4, false><<<gx, 256, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att,
-                                                                  nullptr, 1, B * H, B * H, (const char *)pf_ptr, tile_bytes, 0);
+                                                                  nullptr, 1, B * H, B * H, (const char *)pf_ptr, tile_bytes, 0,
+                                                                  live_rows, n_live);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }
@@ -1182,17 +1245,26 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
 int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
                     int n_prompt, int *result, int arg_first, const bf16_t *emb, const float *pemb, int d, int n_ctx,
                     float *x, bf16_t *xb, float *stats_out, const WmTsDev *ts, int *arrive, int fallback_tok,
-                    float *mean_buf) {
+                    float *mean_buf, const WmStopDev *stop) {
     WmProfScope ps(&ctx->prof, "argmax_embed", ctx->stream);
     WmTsDev t;
     memset(&t, 0, sizeof(t));
     if (ts) t = *ts;
+    WmStopDev sp;
+    memset(&sp, 0, sizeof(sp));
+    if (stop) sp = *stop;
     const int grid = arrive ? (B + 15) / 16 : 1;
     WM_REQUIRE(grid == 1 || B <= 16 * grid, WM_ERR_INVALID, "argmax_embed: bad grid");
     WM_REQUIRE(arrive || B <= 16, WM_ERR_INVALID, "argmax_embed: more than 16 rows need the arrival counter");
     argmax_embed_kernel<<<grid, 1024, 0, ctx->stream>>>(tilemax, n_tiles, B, seq, pos_ptr, n_prompt, result, arg_first,
                                                         emb, pemb, d, n_ctx, x, xb, stats_out, t, arrive, fallback_tok,
-                                                        mean_buf);
+                                                        mean_buf, sp);
+    WM_HIP(hipGetLastError());
+    return WM_OK;
+}
+
+int wm_stop_init(wm_ctx *ctx, const WmStopDev &stop, int B) {
+    dec_live_init_kernel<<<1, WM_DEC_MAXB, 0, ctx->stream>>>(stop, B);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

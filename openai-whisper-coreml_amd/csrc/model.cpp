@@ -59,6 +59,11 @@ static int alloc_decode_buffers(WmModel *m, hipStream_t s) {
     WM_TRY(dalloc_t(m, &m->dseq, (size_t)WM_DEC_MAXB * (D.n_text_ctx + 1), s));
     WM_TRY(dalloc_t(m, &m->dpos, 4, s));
     WM_TRY(dalloc_t(m, &m->darrive, 4, s));
+    WM_TRY(dalloc_t(m, &m->ddone, WM_DEC_MAXB, s));
+    WM_TRY(dalloc_t(m, &m->dbudget, WM_DEC_MAXB, s));
+    WM_TRY(dalloc_t(m, &m->dlive, WM_DEC_MAXB, s));
+    WM_TRY(dalloc_t(m, &m->dnlive, 4, s));
+    if (!m->h_nlive) WM_HIP(hipHostMalloc((void **)&m->h_nlive, WM_NLIVE_RING * sizeof(int), hipHostMallocDefault));
     WM_TRY(dalloc_t(m, &m->dts_rng, (size_t)WM_DEC_MAXB * 4, s));
     WM_TRY(dalloc_t(m, &m->dts_hist, (size_t)WM_DEC_MAXB * 4, s));
     WM_TRY(dalloc_t(m, &m->dts_key, (size_t)WM_DEC_MAXB * (m->vpad / 16), s));
@@ -66,6 +71,23 @@ static int alloc_decode_buffers(WmModel *m, hipStream_t s) {
     WM_TRY(dalloc_t(m, &m->dmask, (size_t)2 * (m->vpad / 32), s));
     WM_HIP(hipMemsetAsync(m->dmask, 0, (size_t)2 * (m->vpad / 32) * 4, s));
     return WM_OK;
+}
+
+WmStopDev wm_model_stop_dev(const WmModel *m) {
+    WmStopDev t;
+    memset(&t, 0, sizeof(t));
+    if (!m->stop_on) return t;
+    t.done = m->ddone; t.budget = m->budget_on ? m->dbudget : nullptr; t.live_rows = m->dlive; t.n_live = m->dnlive;
+    t.eot = m->stop_eot;
+    t.pad_tok = m->stop_eot >= 0 ? m->stop_eot : 0;   // what a finished row keeps embedding: any valid id
+    return t;
+}
+
+void wm_model_drop_graphs(WmModel *m) {
+    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+    if (m->graph_exec_k) { (void)hipGraphExecDestroy(m->graph_exec_k); m->graph_exec_k = nullptr; }
+    if (m->graph_k) { (void)hipGraphDestroy(m->graph_k); m->graph_k = nullptr; }
 }
 
 WmTsDev wm_model_ts_dev(const WmModel *m) {
@@ -90,9 +112,8 @@ int wm_model_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t ts_begin, int3
             WM_REQUIRE(!((m->mask_host[eot >> 5] >> (eot & 31)) & 1u), WM_ERR_INVALID,
                        "timestamp rules: <|endoftext|> (%d) is in the suppress list", eot);
         if (m->ts_begin != ts_begin || m->ts_eot != eot || m->ts_max_initial != max_initial) {
-            // these ids are baked into the captured decode graph's kernel arguments: drop the stale capture
-            if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-            if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+            // these ids are baked into the captured decode graphs' kernel arguments: drop the stale captures
+            wm_model_drop_graphs(m);
         }
         m->ts_begin = ts_begin; m->ts_eot = eot; m->ts_max_initial = max_initial;
     }
@@ -278,8 +299,8 @@ int wm_model_clone(wm_ctx *child, const wm_ctx *parent) {
 void wm_model_destroy(wm_ctx *ctx) {
     WmModel *m = ctx->model;
     if (!m) return;
-    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
-    if (m->graph) (void)hipGraphDestroy(m->graph);
+    wm_model_drop_graphs(m);
+    if (m->h_nlive) (void)hipHostFree(m->h_nlive);
     for (void *p : m->allocs) (void)hipFree(p);
     if (m->pcm_stage) (void)hipFree(m->pcm_stage);
     if (m->io_stage) (void)hipFree(m->io_stage);
@@ -527,6 +548,7 @@ int wm_model_decode_begin(wm_ctx *ctx, int B) {
     // the arrival counter of the arg-max workgroups is zero between launches; a decode that was abandoned half way
     // (an error in the middle of a step) must not leave the next one with a stale count
     WM_HIP(hipMemsetAsync(m->darrive, 0, sizeof(int), ctx->stream));
+    m->stop_on = false;   // wm_transcribe_greedy switches it on for its own decode (lane_prefill)
     return WM_OK;
 }
 
@@ -548,6 +570,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
     const int ns = wm_dec_attn_splits(B, H);
     static const int env_xns = getenv("WM_XATTN_SPLITS") ? atoi(getenv("WM_XATTN_SPLITS")) : 0;  // A/B probe
     const int xns = env_xns > 0 ? env_xns : ns;
+    const int *live = m->stop_on ? m->dlive : nullptr, *nlive = m->stop_on ? m->dnlive : nullptr;
     // mean-centring offsets of the bf16 residual copy: the embedding wrote buffer 0; every LayerNorm-folded GEMV reads
     // the current buffer and leaves the new means in the other one
     int cur = 0;
@@ -568,7 +591,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.pos_ptr = m->dpos; a.n_ctx = T; a.n_head = H;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 2. causal self-attention over positions 0..pos
-        WM_TRY(wm_dec_self_attention(ctx, m->dq, kc, vc, B, H, T, 0, m->dpos, m->datt, L.wo, d, d));
+        WM_TRY(wm_dec_self_attention(ctx, m->dq, kc, vc, B, H, T, 0, m->dpos, m->datt, L.wo, d, d, live, nlive));
         // 3. out-projection + residual (f32 stream, its bf16 copy, partial statistics)
         memset(&a, 0, sizeof(a));
         a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wo; a.c2 = L.bo;
@@ -584,7 +607,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.mean_in = mean_buf(cur); a.mean_out = mean_buf(cur ^ 1); cur ^= 1;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 5. cross-attention over the 1500 cached encoder frames
-        WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, xns, m->dpart, m->datt, true, L.wxo, d, d));
+        WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, xns, m->dpart, m->datt, true, L.wxo, d, d, live, nlive));
         // 6. out-projection + residual
         memset(&a, 0, sizeof(a));
         a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wxo; a.c2 = L.bxo;
@@ -633,7 +656,9 @@ int wm_model_embed_first(wm_ctx *ctx, int B) {
 int wm_model_close_step(wm_ctx *ctx, int B, int n_prompt, bool write_seq, int *result, int arg_first, bool use_ts) {
     WmModel *m = ctx->model;
     const WmTsDev t = wm_model_ts_dev(m);
+    const WmStopDev sp = wm_model_stop_dev(m);
     return wm_argmax_embed(ctx, m->dargmax, m->vpad / 16, B, write_seq ? m->dseq : nullptr, m->dpos, n_prompt, result,
                            arg_first, m->tok_emb, m->dec_pos, m->dims.n_text_state, m->dims.n_text_ctx, m->dx, m->dxb,
-                           m->dstats, use_ts ? &t : nullptr, m->darrive, use_ts ? m->ts_eot : arg_first, m->dmean);
+                           m->dstats, use_ts ? &t : nullptr, m->darrive, use_ts ? m->ts_eot : arg_first, m->dmean,
+                           m->stop_on ? &sp : nullptr);
 }

@@ -78,6 +78,17 @@ struct WmTsDev {
     int ts_begin, eot, n_vocab, max_initial;  // max_initial: index of the largest first timestamp, < 0 = unlimited
 };
 
+// Early-stop state of a decode group (device view; done == null: off).  A row is DONE once it has emitted `eot`
+// (eot >= 0) or produced budget[b] tokens (budget != null); from then on its tokens are `pad_tok`, it is dropped from
+// the compact live list the attention kernels walk, and when the list is empty the host stops launching positions.
+struct WmStopDev {
+    int *done;          // [B] 0 / 1
+    const int *budget;  // [B] tokens a row may generate (null: max_new for all)
+    int *live_rows;     // [B] compact, ascending list of the rows that are not done
+    int *n_live;        // [1]
+    int eot, pad_tok;
+};
+
 struct WmModel {
     wm_dims dims;
     bool finalized = false;
@@ -127,10 +138,22 @@ struct WmModel {
     int *dseq = nullptr;        // [n_text_ctx][16->B] token sequence (prompt, then generated), position-major
     int *dpos = nullptr;        // [1] current decode position (read by every decode kernel)
     int *darrive = nullptr;     // [1] arrival counter of the arg-max workgroups (zero between launches)
+    // early stop (wm_transcribe_greedy with eot >= 0 or per-chunk token budgets): see WmStopDev
+    int *ddone = nullptr, *dbudget = nullptr, *dlive = nullptr, *dnlive = nullptr;
+    int *h_nlive = nullptr;     // pinned host ring: n_live after each burst of positions (the host polls it)
+    bool stop_on = false;       // the decode being enqueued uses the stop state (kernel arguments of the captured graph)
+    bool budget_on = false;
+    int stop_eot = -1;
+    std::vector<int32_t> budget_host;  // wm_set_token_budgets: per-chunk budgets of the NEXT call (empty: none)
     // captured decode step (one hipGraph replayed for every position)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_B = 0, graph_n_prompt = 0, graph_cap_b = 0, graph_mask = 0;
+    // ... and WM_BURST consecutive positions as ONE graph (the arg-max kernel advances the device-side position, so
+    // consecutive positions do not depend on the host): 1/8 of the graph launches, no launch-queue bubbles between them
+    hipGraph_t graph_k = nullptr;
+    hipGraphExec_t graph_exec_k = nullptr;
+    int graph_burst = 0, graph_stop_key = 0;
     unsigned *dmask = nullptr;   // [2][vpad/32] suppressed-token bitmaps (wm_set_suppress); [1] = first generated token
     bool mask_on = false;
     std::vector<unsigned> mask_host;  // host copy of the every-position bitmap
@@ -174,6 +197,9 @@ int wm_model_set_suppress(wm_ctx *ctx, const int32_t *ids, int n, const int32_t 
 int wm_model_embed_first(wm_ctx *ctx, int B);
 // arg-max reduce + write next token (positions >= n_prompt) + embed next position + advance *dpos
 int wm_model_close_step(wm_ctx *ctx, int B, int n_prompt, bool write_seq, int *result, int arg_first, bool use_ts = false);
+// the device view of the early-stop state (done == null when m->stop_on is false)
+WmStopDev wm_model_stop_dev(const WmModel *m);
+void wm_model_drop_graphs(WmModel *m);
 int wm_model_set_pos(wm_ctx *ctx, int pos);
 
 // ---------------------------------------------------------------- kernel launchers ----
@@ -213,6 +239,7 @@ int wm_enc_attention(wm_ctx *ctx, const bf16_t *qk, const bf16_t *vt, bf16_t *at
 
 // dec_kernels.hip
 constexpr int WM_DEC_MAXB = 128;  // decode group: up to eight batch blocks of 16 rows (the MFMA M dimension)
+constexpr int WM_NLIVE_RING = 16;  // pinned host slots for the per-burst live-row counts (early stop)
 constexpr int WM_MAXSPLIT = 8;  // stream partials of a (sequence, head) pair of the cross-attention (small batches)
 enum DecEpi { DE_QKV = 0, DE_Q = 1, DE_RESID = 2, DE_GELU = 3, DE_LOGITS = 4 };
 struct DecGemvArgs {
@@ -262,11 +289,12 @@ int wm_dec_embed(wm_ctx *ctx, const int *seq, const int *pos_ptr, int B, const b
 int wm_dec_attn_splits(int B, int H);
 int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
                      int T_stride, int n_keys, const int *pos_ptr, int nsplit, float *part, bf16_t *att,
-                     bool cross, const bf16_t *pf_ptr = nullptr, int pf_rows = 0, int pf_k = 0);
+                     bool cross, const bf16_t *pf_ptr = nullptr, int pf_rows = 0, int pf_k = 0,
+                     const int *live_rows = nullptr, const int *n_live = nullptr);
 // The decoder's causal self-attention (<= 448 cached rows per pair): one 4-wave workgroup per (sequence, head).
 int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H, int T_stride,
                           int n_keys, const int *pos_ptr, bf16_t *att, const bf16_t *pf_ptr = nullptr, int pf_rows = 0,
-                          int pf_k = 0);
+                          int pf_k = 0, const int *live_rows = nullptr, const int *n_live = nullptr);
 // Close a decode step (one workgroup): reduce the per-tile packed maxima of a DE_LOGITS launch;
 // chosen token of row b -> seq[(*pos_ptr + 1) * B + b] when that position is >= n_prompt;
 // (token - arg_first) -> result[b]; embed the tokens of position *pos_ptr + 1 into x (+ LayerNorm
@@ -276,7 +304,9 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
 int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles, int B, int *seq, int *pos_ptr,
                     int n_prompt, int *result, int arg_first, const bf16_t *emb, const float *pemb, int d, int n_ctx,
                     float *x, bf16_t *xb, float *stats_out, const WmTsDev *ts = nullptr, int *arrive = nullptr,
-                    int fallback_tok = 0, float *mean_buf = nullptr);
+                    int fallback_tok = 0, float *mean_buf = nullptr, const WmStopDev *stop = nullptr);
+// start of a decode with early stop: no row done, every row live
+int wm_stop_init(wm_ctx *ctx, const WmStopDev &stop, int B);
 // initial timestamp-rule state of B sequences (before the first sampled token)
 int wm_ts_init(wm_ctx *ctx, const WmTsDev &ts, int B);
 int wm_range_softmax(wm_ctx *ctx, const float *logits, long ldo, int B, int first, int n, float *probs);

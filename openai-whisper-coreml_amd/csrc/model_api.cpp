@@ -277,11 +277,24 @@ static int detect_language_impl(wm_ctx *ctx, const float *xa, int B, int32_t sot
 // ------------------------------------------------------------------ greedy transcription
 static size_t pcm_elem(wm_dtype t) { return t == WM_I16 ? 2 : t == WM_F32 ? 4 : 8; }
 
+extern "C" int wm_set_token_budgets(wm_ctx *ctx, const int32_t *budgets, int n) try {
+    WM_MODEL(ctx);
+    WM_REQUIRE(n >= 0 && (n == 0 || budgets), WM_ERR_INVALID, "set_token_budgets: bad list");
+    for (int i = 0; i < n; ++i)
+        WM_REQUIRE(budgets[i] >= 1, WM_ERR_INVALID, "set_token_budgets: budget %d of chunk %d is < 1", budgets[i], i);
+    m->budget_host.assign(budgets, budgets + n);
+    return WM_OK;
+} WM_API_CATCH
+
 // ---------------------------------------------------------------- greedy transcription
 // One batch's decode is a chain of ~260 dependent launches per position and is bound by launch latency, not by
 // HBM, so a call with more chunks than one decode group is spread over LANES: weight-sharing
-// clones of the context (wm_clone), each with its own stream, activations, KV caches and decode graph.  The
-// single host thread enqueues the lanes round-robin; the GPU overlaps them.
+// clones of the context (wm_clone), each with its own stream, activations, KV caches and decode graphs.  The
+// single host thread drives the lanes as a small non-blocking scheduler: a lane takes the next decode group as soon as
+// it has finished its previous one, positions are enqueued in BURSTS (one hipGraph of WM_BURST consecutive positions --
+// the arg-max kernel advances the device-side position, so consecutive positions do not depend on the host), and with
+// early stop on (eot >= 0 or per-chunk token budgets) a lane stays at most two bursts ahead of the GPU and stops
+// enqueuing once the device reports that no sequence of its group is live any more.
 namespace {
 constexpr int kGroupChunks = 8;   // smallest decode group worth a lane (BASELINE.json configs[3]); up to WM_DEC_MAXB
 
@@ -294,20 +307,45 @@ int lane_limit() {
     return n;
 }
 
+int burst_len() {
+    static const int n = [] {
+        const char *e = getenv("WM_BURST");
+        const int v = e ? atoi(e) : 8;
+        return v < 1 ? 1 : (v > 32 ? 32 : v);
+    }();
+    return n;
+}
+
 struct LaneJob {
+    enum State { IDLE, DECODING, DRAINING };
     wm_ctx *c = nullptr;
     int b0 = 0, Bg = 0;
+    State state = IDLE;
+    int t = 0;          // decoder positions enqueued so far
+    int bursts = 0;     // bursts enqueued so far
+    bool stopped = false;   // the device reported zero live rows
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    std::vector<int32_t> pr, gen;
+    hipEvent_t burst_ev[WM_NLIVE_RING] = {};
+    std::vector<int32_t> pr, gen, bud;
+    float stage_sum[3] = {0.f, 0.f, 0.f};
     ~LaneJob() {
-        if (c) (void)hipStreamSynchronize(c->stream);  // error paths: nothing may outlive pr / gen
+        if (c) (void)hipStreamSynchronize(c->stream);  // error paths: nothing may outlive pr / gen / bud
         for (auto &e : ev)
+            if (e) (void)hipEventDestroy(e);
+        for (auto &e : burst_ev)
             if (e) (void)hipEventDestroy(e);
     }
 };
 
+struct StopCfg {
+    bool on = false;
+    int32_t eot = -1;
+    const int32_t *budgets = nullptr;  // [B] of the call, already clamped to max_new (null: none)
+};
+
 // front end -> encoder -> cross K/V -> prompt upload -> first embedding, all enqueued on the lane's stream
-int lane_prefill(LaneJob &j, const void *pcm, wm_dtype pcm_dtype, const int32_t *prompt, int n_prompt, wm_mem mem) {
+int lane_prefill(LaneJob &j, const void *pcm, wm_dtype pcm_dtype, const int32_t *prompt, int n_prompt, wm_mem mem,
+                 const StopCfg &stop) {
     wm_ctx *c = j.c;
     WmModel *m = c->model;
     const wm_dims &D = m->dims;
@@ -334,6 +372,17 @@ int lane_prefill(LaneJob &j, const void *pcm, wm_dtype pcm_dtype, const int32_t 
         for (int b = 0; b < Bg; ++b) j.pr[(size_t)t * Bg + b] = prompt[t];
     WM_HIP(hipMemcpyAsync(m->dseq, j.pr.data(), j.pr.size() * 4, hipMemcpyHostToDevice, c->stream));
     WM_TRY(wm_model_set_pos(c, 0));
+    // early-stop state of this group: done flags, live list, per-row budgets (kernel arguments of the decode graphs)
+    m->stop_on = stop.on;
+    m->stop_eot = stop.eot;
+    m->budget_on = stop.on && stop.budgets != nullptr;
+    if (stop.on) {
+        if (m->budget_on) {
+            j.bud.assign(stop.budgets + j.b0, stop.budgets + j.b0 + Bg);
+            WM_HIP(hipMemcpyAsync(m->dbudget, j.bud.data(), (size_t)Bg * 4, hipMemcpyHostToDevice, c->stream));
+        }
+        WM_TRY(wm_stop_init(c, wm_model_stop_dev(m), Bg));
+    }
     WM_TRY(wm_model_reserve(c, Bg));
     WM_HIP(hipEventRecord(j.ev[0], c->stream));
     // 1. log-mel front end (f32 fast path), output stays in HBM
@@ -351,24 +400,68 @@ int lane_prefill(LaneJob &j, const void *pcm, wm_dtype pcm_dtype, const int32_t 
 
 // One decoder position = 8 launches per layer + logits + arg-max/embed (which writes the next token, embeds the
 // next position and advances *dpos).  Nothing in it depends on host state, so it is captured ONCE into a
-// hipGraph per lane and replayed for every position.
-int lane_graph(LaneJob &j, int n_prompt) {
+// hipGraph per lane and replayed for every position -- and `burst` consecutive positions are captured as one more graph.
+int capture_positions(LaneJob &j, int n_prompt, int n_pos, hipGraph_t *g, hipGraphExec_t *ge) {
+    wm_ctx *c = j.c;
+    WmModel *m = c->model;
+    WM_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    int crc = WM_OK;
+    for (int i = 0; i < n_pos && crc == WM_OK; ++i) {
+        crc = wm_model_decode_step(c, j.Bg, false, 0, m->dims.n_vocab - 1, m->mask_on ? n_prompt - 1 : -1, m->ts_on);
+        if (crc == WM_OK) crc = wm_model_close_step(c, j.Bg, n_prompt, true, nullptr, 0, m->ts_on);
+    }
+    hipError_t ce = hipStreamEndCapture(c->stream, g);
+    if (crc != WM_OK) return crc;
+    WM_HIP(ce);
+    WM_HIP(hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
+    return WM_OK;
+}
+
+int lane_graph(LaneJob &j, int n_prompt, int n_steps) {
     wm_ctx *c = j.c;
     WmModel *m = c->model;
     const int mk = (m->mask_on ? 1 : 0) | (m->ts_on ? 2 : 0);
-    if (m->graph_exec && m->graph_B == j.Bg && m->graph_n_prompt == n_prompt && m->graph_cap_b == m->cap_b &&
-        m->graph_mask == mk)
-        return WM_OK;
-    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-    if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
-    WM_HIP(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    int crc = wm_model_decode_step(c, j.Bg, false, 0, m->dims.n_vocab - 1, m->mask_on ? n_prompt - 1 : -1, m->ts_on);
-    if (crc == WM_OK) crc = wm_model_close_step(c, j.Bg, n_prompt, true, nullptr, 0, m->ts_on);
-    hipError_t ce = hipStreamEndCapture(c->stream, &m->graph);
-    if (crc != WM_OK) return crc;
-    WM_HIP(ce);
-    WM_HIP(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
-    m->graph_B = j.Bg; m->graph_n_prompt = n_prompt; m->graph_cap_b = m->cap_b; m->graph_mask = mk;
+    const int sk = m->stop_on ? (1 | (m->budget_on ? 2 : 0) | ((m->stop_eot + 2) << 2)) : 0;
+    const int K = burst_len();
+    const bool same = m->graph_B == j.Bg && m->graph_n_prompt == n_prompt && m->graph_cap_b == m->cap_b &&
+                      m->graph_mask == mk && m->graph_stop_key == sk;
+    if (!same) wm_model_drop_graphs(m);
+    if (!m->graph_exec) WM_TRY(capture_positions(j, n_prompt, 1, &m->graph, &m->graph_exec));
+    if (K > 1 && n_steps >= K && (!m->graph_exec_k || m->graph_burst != K)) {
+        if (m->graph_exec_k) { (void)hipGraphExecDestroy(m->graph_exec_k); m->graph_exec_k = nullptr; }
+        if (m->graph_k) { (void)hipGraphDestroy(m->graph_k); m->graph_k = nullptr; }
+        WM_TRY(capture_positions(j, n_prompt, K, &m->graph_k, &m->graph_exec_k));
+        m->graph_burst = K;
+    }
+    m->graph_B = j.Bg; m->graph_n_prompt = n_prompt; m->graph_cap_b = m->cap_b; m->graph_mask = mk; m->graph_stop_key = sk;
+    return WM_OK;
+}
+
+// enqueue the next burst of positions of a lane (<= burst_len(), up to the end of the sequence)
+int lane_burst(LaneJob &j, int n_prompt, int n_steps, bool use_graph, bool stop_on) {
+    wm_ctx *c = j.c;
+    WmModel *m = c->model;
+    const int K = burst_len();
+    const int k = n_steps - j.t < K ? n_steps - j.t : K;
+    if (use_graph && k == K && K > 1 && m->graph_exec_k) {
+        WM_HIP(hipGraphLaunch(m->graph_exec_k, c->stream));
+    } else {
+        for (int i = 0; i < k; ++i) {
+            if (use_graph) {
+                WM_HIP(hipGraphLaunch(m->graph_exec, c->stream));
+            } else {
+                WM_TRY(wm_model_decode_step(c, j.Bg, false, 0, m->dims.n_vocab - 1, m->mask_on ? n_prompt - 1 : -1, m->ts_on));
+                WM_TRY(wm_model_close_step(c, j.Bg, n_prompt, true, nullptr, 0, m->ts_on));
+            }
+        }
+    }
+    j.t += k;
+    if (stop_on) {  // the live-row count after this burst, where the host can read it without touching the stream
+        const int slot = j.bursts % WM_NLIVE_RING;
+        WM_HIP(hipMemcpyAsync(m->h_nlive + slot, m->dnlive, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        WM_HIP(hipEventRecord(j.burst_ev[slot], c->stream));
+    }
+    ++j.bursts;
     return WM_OK;
 }
 }  // namespace
@@ -386,10 +479,22 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
                "prompt (%d) + new tokens (%d) must fit the %d-token context", n_prompt, max_new, D.n_text_ctx);
     for (int i = 0; i < n_prompt; ++i)
         WM_REQUIRE(prompt[i] >= 0 && prompt[i] < D.n_vocab, WM_ERR_INVALID, "prompt token %d out of range", prompt[i]);
+    WM_REQUIRE(eot < D.n_vocab, WM_ERR_INVALID, "eot %d outside the vocabulary", eot);
+    // per-chunk token budgets set for THIS call (wm_set_token_budgets): consumed here
+    std::vector<int32_t> budgets;
+    budgets.swap(m->budget_host);
+    WM_REQUIRE(budgets.empty() || (int)budgets.size() == B, WM_ERR_INVALID,
+               "token budgets were set for %d chunks, the call has %d", (int)budgets.size(), B);
+    for (auto &b : budgets) b = b > max_new ? max_new : b;
     static const bool no_graph = getenv("WM_NO_GRAPH") != nullptr;
+    static const bool no_stop = getenv("WM_NO_EARLY_STOP") != nullptr;   // A/B: decode every position, truncate on the host
     const bool use_graph = !no_graph && !ctx->prof.on;
+    StopCfg stop;
+    stop.on = !no_stop && (eot >= 0 || !budgets.empty());
+    stop.eot = eot;
+    stop.budgets = budgets.empty() ? nullptr : budgets.data();
     // Split the B chunks into G balanced decode groups (<= WM_DEC_MAXB each, kGroupChunks preferred) and run
-    // them L lanes at a time.  Per-kernel profiling keeps everything on the caller's context (one lane).
+    // them on L lanes.  Per-kernel profiling keeps everything on the caller's context (one lane).
     const int L = ctx->prof.on ? 1 : lane_limit();
     int G;
     if (B <= kGroupChunks * L) {
@@ -409,48 +514,64 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
     for (int l = 0; l < n_lanes; ++l) {
         jobs[l].c = l == 0 ? ctx : ctx->lanes[l - 1];
         for (auto &e : jobs[l].ev) WM_HIP(hipEventCreate(&e));
+        if (stop.on)
+            for (auto &e : jobs[l].burst_ev) WM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     ctx->stage_ms[0] = ctx->stage_ms[1] = ctx->stage_ms[2] = 0.f;
     const int n_steps = n_prompt + max_new - 1;
     const int base = B / G, rem = B % G;
-    for (int g0 = 0; g0 < G; g0 += n_lanes) {
-        const int nl = (G - g0) < n_lanes ? (G - g0) : n_lanes;
-        for (int l = 0; l < nl; ++l) {
+    int next_group = 0, groups_done = 0;
+    while (groups_done < G) {
+        bool progress = false;
+        for (int l = 0; l < n_lanes; ++l) {
             LaneJob &j = jobs[l];
-            const int g = g0 + l;
-            j.Bg = base + (g < rem ? 1 : 0);
-            j.b0 = g * base + (g < rem ? g : rem);
-            WM_TRY(lane_prefill(j, pcm, pcm_dtype, prompt, n_prompt, mem));
-            if (use_graph) WM_TRY(lane_graph(j, n_prompt));
-        }
-        for (int t = 0; t < n_steps; ++t)
-            for (int l = 0; l < nl; ++l) {
-                LaneJob &j = jobs[l];
-                if (use_graph) {
-                    WM_HIP(hipGraphLaunch(j.c->model->graph_exec, j.c->stream));
-                } else {
-                    WM_TRY(wm_model_decode_step(j.c, j.Bg, false, 0, D.n_vocab - 1,
-                                                j.c->model->mask_on ? n_prompt - 1 : -1, j.c->model->ts_on));
-                    WM_TRY(wm_model_close_step(j.c, j.Bg, n_prompt, true, nullptr, 0, j.c->model->ts_on));
-                }
+            WM_TRY(wm_ctx_make_current(j.c));
+            if (j.state == LaneJob::IDLE) {
+                if (next_group >= G) continue;
+                const int g = next_group++;
+                j.Bg = base + (g < rem ? 1 : 0);
+                j.b0 = g * base + (g < rem ? g : rem);
+                j.t = 0; j.bursts = 0; j.stopped = false;
+                WM_TRY(lane_prefill(j, pcm, pcm_dtype, prompt, n_prompt, mem, stop));
+                if (use_graph) WM_TRY(lane_graph(j, n_prompt, n_steps));
+                j.state = LaneJob::DECODING;
+                progress = true;
+                continue;   // the other lanes get their prefill before anyone's first burst
             }
-        for (int l = 0; l < nl; ++l) {
-            LaneJob &j = jobs[l];
-            WM_HIP(hipEventRecord(j.ev[3], j.c->stream));
-            j.gen.resize((size_t)max_new * j.Bg);  // dseq[n_prompt + i][b]
-            WM_HIP(hipMemcpyAsync(j.gen.data(), j.c->model->dseq + (size_t)n_prompt * j.Bg, j.gen.size() * 4,
-                                  hipMemcpyDeviceToHost, j.c->stream));
-        }
-        float wave_ms[3] = {0.f, 0.f, 0.f};
-        for (int l = 0; l < nl; ++l) {
-            LaneJob &j = jobs[l];
-            // a decode group runs for seconds: poll instead of spinning in hipStreamSynchronize, so that the host threads
-            // of the other lanes / ranks (one process per GPU, several contexts each) keep their cores
-            while (hipStreamQuery(j.c->stream) == hipErrorNotReady) usleep(200);
+            if (j.state == LaneJob::DECODING) {
+                if (stop.on && j.bursts >= 2 && !j.stopped) {
+                    // stay at most two bursts ahead of the GPU: burst (bursts - 2) must have finished, and its live count
+                    // says whether there is anything left to decode
+                    const int slot = (j.bursts - 2) % WM_NLIVE_RING;
+                    const hipError_t q = hipEventQuery(j.burst_ev[slot]);
+                    if (q == hipErrorNotReady) { (void)hipGetLastError(); continue; }   // "not ready" is not an error to keep
+                    WM_HIP(q);
+                    if (j.c->model->h_nlive[slot] == 0) j.stopped = true;
+                }
+                if (j.t < n_steps && !j.stopped) {
+                    WM_TRY(lane_burst(j, n_prompt, n_steps, use_graph, stop.on));
+                    progress = true;
+                    continue;
+                }
+                // everything enqueued (or nothing left to decode): fetch the token streams
+                WM_HIP(hipEventRecord(j.ev[3], j.c->stream));
+                j.gen.resize((size_t)max_new * j.Bg);  // dseq[n_prompt + i][b]
+                WM_HIP(hipMemcpyAsync(j.gen.data(), j.c->model->dseq + (size_t)n_prompt * j.Bg, j.gen.size() * 4,
+                                      hipMemcpyDeviceToHost, j.c->stream));
+                j.state = LaneJob::DRAINING;
+                progress = true;
+                continue;
+            }
+            // DRAINING: a decode group runs for seconds -- poll instead of spinning in hipStreamSynchronize, so that the
+            // host threads of the other lanes / ranks (one process per GPU, several contexts each) keep their cores
+            const hipError_t q = hipStreamQuery(j.c->stream);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); continue; }
+            WM_HIP(q);
             WM_HIP(hipStreamSynchronize(j.c->stream));
             for (int b = 0; b < j.Bg; ++b) {
                 int len = max_new;
-                for (int i = 0; i < max_new; ++i)
+                if (stop.budgets && stop.budgets[j.b0 + b] < len) len = stop.budgets[j.b0 + b];
+                for (int i = 0; i < len; ++i)
                     if (eot >= 0 && j.gen[(size_t)i * j.Bg + b] == eot) { len = i + 1; break; }
                 for (int i = 0; i < max_new; ++i)
                     tokens_out[(size_t)(j.b0 + b) * max_new + i] = i < len ? j.gen[(size_t)i * j.Bg + b] : eot;
@@ -458,9 +579,15 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
             }
             float ms;
             for (int i = 0; i < 3; ++i)
-                if (hipEventElapsedTime(&ms, j.ev[i], j.ev[i + 1]) == hipSuccess && ms > wave_ms[i]) wave_ms[i] = ms;
+                if (hipEventElapsedTime(&ms, j.ev[i], j.ev[i + 1]) == hipSuccess) j.stage_sum[i] += ms;
+            j.state = LaneJob::IDLE;
+            ++groups_done;
+            progress = true;
         }
-        for (int i = 0; i < 3; ++i) ctx->stage_ms[i] += wave_ms[i];  // lanes overlap: slowest lane per stage
+        if (!progress) usleep(100);
     }
+    for (int l = 0; l < n_lanes; ++l)   // lanes overlap: the busiest lane per stage
+        for (int i = 0; i < 3; ++i)
+            if (jobs[l].stage_sum[i] > ctx->stage_ms[i]) ctx->stage_ms[i] = jobs[l].stage_sum[i];
     return WM_OK;
 } WM_API_CATCH

@@ -290,6 +290,12 @@ def test_tiny_en_dimensions(pkg):
     e2 = R.rel_l2(lg, ref)
     print("tiny.en logits rel-L2", e2)
     assert e2 <= LOGIT_TOL
+    # BASELINE.json configs[1] as written: greedy decode of a single chunk (the flat cross-attention launch + combine,
+    # 6 heads x 1 sequence), every choice against the oracle teacher-forced on the GPU's prefix
+    prompt = [50257, 50362]
+    gen, lens = ctx.transcribe_greedy(pcm, prompt, 8)
+    assert gen.shape == (1, 8) and lens.tolist() == [8]
+    _check_greedy_against_teacher_forced_oracle(sd, dims, want, prompt, gen)
     ctx.close()
 
 
@@ -351,8 +357,14 @@ def test_base_geometry_batch32(pkg):
     sd = R.to_torch({n: ctx.get_tensor(n, s) for n, s, _ in W.tensor_specs(dims)})
     want = R.encode(sd, dims, mel[:2]).numpy()
     assert R.rel_l2(xa[:2], want) <= ENC_TOL
-    toks, lens = ctx.transcribe_greedy(pcm, [50258, 50259, 50359, 50363], 4)
+    prompt = [50258, 50259, 50359, 50363]
+    toks, lens = ctx.transcribe_greedy(pcm, prompt, 4)
     assert toks.shape == (32, 4) and np.array_equal(toks[0], toks[4]) and np.array_equal(toks[17], toks[21])
+    # the greedy choices of the B = 32 run against the oracle: rows from both batch blocks of the decode groups
+    rows = [0, 1, 2, 3, 17, 30]
+    want6 = R.encode(sd, dims, mel[rows]).numpy()
+    assert R.rel_l2(xa[rows], want6) <= ENC_TOL
+    _check_greedy_against_teacher_forced_oracle(sd, dims, want6, prompt, toks[rows])
     ctx.close()
 
 
@@ -700,8 +712,9 @@ def _oracle_weights(ctx, dims):
     return R.to_torch({n: ctx.get_tensor(n, s) for n, s, _ in W.tensor_specs(dims)})
 
 
-def _check_greedy_against_teacher_forced_oracle(sd, dims, xa_ref, prompt, toks):
-    """Every token the GPU chose must be (within MARGIN) the oracle's arg-max given the same prefix."""
+def _check_greedy_against_teacher_forced_oracle(sd, dims, xa_ref, prompt, toks, scaled=False):
+    """Every token the GPU chose must be (within MARGIN; scaled=True: within _scaled_margin of the row) the oracle's
+    arg-max given the same prefix."""
     Bn, n_new = toks.shape
     seq = np.concatenate([np.tile(np.asarray(prompt, np.int32), (Bn, 1)), toks], axis=1).astype(np.int32)
     ref = R.decode_logits(sd, dims, seq[:, :-1], xa_ref).numpy()          # logits at position p choose token p + 1
@@ -711,7 +724,8 @@ def _check_greedy_against_teacher_forced_oracle(sd, dims, xa_ref, prompt, toks):
             row = ref[b, len(prompt) - 1 + i]
             gap = float(row.max() - row[toks[b, i]])
             worst = max(worst, gap)
-            assert gap <= MARGIN, "chunk %d, new token %d: GPU picked %d, oracle gap %g" % (b, i, toks[b, i], gap)
+            mg = _scaled_margin(row) if scaled else MARGIN
+            assert gap <= mg, "chunk %d, new token %d: GPU picked %d, oracle gap %g" % (b, i, toks[b, i], gap)
     return worst
 
 
@@ -886,11 +900,16 @@ def test_timestamp_rule_change_invalidates_the_captured_graph(lively):
         a, _ = ctx.transcribe_greedy(pcm, prompt, 8)
         ctx.set_timestamp_rules(True, 300, 7, 20)
         b, _ = ctx.transcribe_greedy(pcm, prompt, 8)
-        want_b, _, _ = R.greedy(sd, dims, R.encode(sd, dims, ctx.logmel(pcm, out_dtype=np.float32)).numpy(), prompt, 8,
-                                ts_rules=dict(ts_begin=300, eot=7, max_initial=20))
-        assert b[:, 0].min() >= 300                         # the transcript opens with a timestamp of the NEW range
-        assert not np.array_equal(a, b) or a[:, 0].min() >= 400
-        assert (b[:, 0] == want_b[:, 0]).all() or True      # choices are margin-checked elsewhere; here: the rule ids
+        assert a[:, 0].min() >= 400 and a[:, 0].max() <= 400 + 20   # first run: opens inside ITS initial-timestamp window
+        # the transcript opens with a timestamp of the NEW range: [300, 300 + max_initial] -- disjoint from the old
+        # window [400, 420], so a replay of the stale capture cannot pass
+        assert b[:, 0].min() >= 300 and b[:, 0].max() <= 300 + 20
+        # ... and it is the oracle's choice under the new ids (margin rule), teacher-forced on the GPU's own encoder output
+        xa = ctx.encode_mel(ctx.logmel(pcm, out_dtype=np.float32))
+        for r in range(2):
+            row = R.decode_logits(sd, dims, np.asarray(prompt)[None], xa[r:r + 1])[0, -1].clone()
+            R.timestamp_filter(row, [], 300, 7, 20)
+            _check_choice(row.numpy(), int(b[r, 0]))
     finally:
         ctx.set_timestamp_rules(False)
 
@@ -986,3 +1005,266 @@ def test_layernorm_fold_is_robust_to_a_common_mode_offset(pkg):
         _check_greedy_against_teacher_forced_oracle(sd, dims, xa, [10, 21, 5, 7], toks)
         ctx.close()
     assert max(errs) <= 2.0 * errs[0] + 1e-3, errs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 3: the decode policy at the PRODUCTION vocabulary, and the widths between base and large (VERDICT r2 / ADVICE r2)
+def _lively_on_device(ctx, dims, gain=4.0):
+    """The `lively` recipe for models too big to generate on the host: every matrix (not the positional tables) of the
+    device-generated synthetic weights scaled by a power of two (still bf16-exact), so that the token streams depend on
+    the audio and on the decode history."""
+    for name, shape, kind in W.tensor_specs(dims):
+        if kind == W.K_MATRIX and "positional" not in name:
+            ctx.set_tensor(name, ctx.get_tensor(name, shape) * np.float32(gain))
+
+
+def _openai_like_suppress_list(n_vocab, specials):
+    """A suppress list shaped like openai-whisper's `non_speech_tokens` + specials (about 90 ids): scattered ordinary ids,
+    the special tokens, and ids inside the LAST, partial 16-column tile of the vocabulary."""
+    rng = np.random.default_rng(50257)
+    scattered = sorted({int(t) for t in rng.integers(1, 50256, size=82)})
+    last_tile = (n_vocab - 1) // 16 * 16
+    return sorted(set(scattered) | set(specials) | {last_tile + 1, n_vocab - 1})
+
+
+def _scaled_margin(row):
+    """Arg-max margin in logit units for a model whose logits are not O(1): MARGIN (0.05) was set on models with logit
+    rms <= 1; the `lively` production-shape model has rms ~2.9 (matrices x 4), and the stated value tolerance is
+    RELATIVE (rel-L2 <= 1e-2), so the admissible gap scales with the row: 5 % of its rms, never below MARGIN."""
+    fin = row[np.isfinite(row)]
+    return max(MARGIN, 0.05 * float(np.sqrt(np.mean(fin.astype(np.float64) ** 2)))) if fin.size else MARGIN
+
+
+def _check_policy_choices(sd, dims, xa_rows, prompt, got, suppress, suppress_first, TS, EOT, MAXI):
+    """Every choice of `got` against the oracle's filtered logits, teacher-forced on the GPU's own history -- the
+    production-shape twin of test_timestamp_rules_follow_the_oracle (margins scaled to the logit rms)."""
+    n_forced = n_near = 0
+    n_new = got.shape[1]
+    for b in range(got.shape[0]):
+        seq = np.concatenate([prompt, got[b]])[None, :-1]
+        ref = R.decode_logits(sd, dims, seq, xa_rows[b:b + 1])[0]
+        for i in range(n_new):
+            row = ref[len(prompt) - 1 + i].clone()
+            row[suppress] = float("-inf")
+            if i == 0:
+                row[suppress_first] = float("-inf")
+            unforced = row.clone()
+            mg = _scaled_margin(ref[len(prompt) - 1 + i].numpy())
+            forced, gap = R.timestamp_filter(row, [int(t) for t in got[b, :i]], TS, EOT, MAXI)
+            n_forced += forced
+            choice = int(got[b, i])
+            if abs(gap) < mg:                # the summed-probability rule is a near-tie: either branch is right
+                n_near += 1
+                R.timestamp_filter(unforced, [int(t) for t in got[b, :i]], TS, EOT, MAXI, sum_rule=False)
+                only_ts = unforced.clone()
+                only_ts[:TS] = float("-inf")
+                ok = float(only_ts.max() - only_ts[choice]) <= mg or float(unforced.max() - unforced[choice]) <= mg
+                assert ok, (b, i, choice)
+            else:
+                r = row.numpy()
+                g = float(r.max() - r[choice])
+                assert g <= mg, "chunk %d, new token %d: GPU picked %d, oracle gap %g (margin %g)" % (b, i, choice, g, mg)
+    return n_forced, n_near
+
+
+@pytest.mark.parametrize("model,TS", [("large-v2", 50364), ("large-v3", 50365)])
+def test_decode_policy_at_the_production_vocabulary(pkg, model, TS):
+    """VERDICT r2 "weak" #2 / next #1a: SuppressTokens + SuppressBlank + ApplyTimestampRules at the shapes they run at in
+    production -- vocabulary 51 865 / 51 866 = 3 242 tiles of 16 columns, timestamp_begin 50 364 / 50 365 (t_first =
+    ts_begin >> 4 with a partial first tile: 50364 % 16 = 12, 50365 % 16 = 13), 1 501 timestamp ids over 94 tiles, the
+    wide (TN = 4, NBLK = 2) logits launch and more than 16 rows through the multi-workgroup arg-max arrival counter --
+    for decode groups of 8, 17 and 40 rows.  d = 1280, 20 heads, two layers (the oracle stays fast); every choice of
+    the 8 distinct chunks is checked with R.timestamp_filter, the larger groups must reproduce those rows bit for bit."""
+    import torch
+    dims = dict(pkg.binding.MODEL_DIMS[model], n_audio_layer=2, n_text_layer=2)
+    V = dims["n_vocab"]
+    EOT, SOT, MAXI, NEW = 50257, 50258, 50, 20
+    ctx = pkg.binding.Context(dims)
+    ctx.init_synthetic(29)
+    _perturb_ln_on_device(ctx, dims, seed=6)
+    _lively_on_device(ctx, dims)
+    ctx.finalize()
+    sd = _oracle_weights(ctx, dims)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    lang_last = SOT + (100 if model == "large-v3" else 99)
+    specials = [SOT, lang_last + 1, lang_last + 2, lang_last + 3, lang_last + 4, lang_last + 5, TS - 1]  # translate .. notimestamps
+    assert TS - 1 == lang_last + 6 and TS + 1500 == V - 1
+    suppress = _openai_like_suppress_list(V, specials)
+    assert len(suppress) >= 88 and max(suppress) == V - 1 and (V - 1) // 16 == (V + 15) // 16 - 1
+    prompt = [SOT, SOT + 1, lang_last + 2]            # sot, <|en|>, <|transcribe|>: decoding WITH timestamps
+    pcm = tones(8)
+    mel = ctx.logmel(pcm, n_mels=dims["n_mels"], out_dtype=np.float32)
+    ctx.set_suppress(suppress, [220, EOT])            # SuppressBlank: " " and <|endoftext|>
+    ctx.set_timestamp_rules(True, TS, EOT, MAXI)
+    try:
+        got, lens = ctx.transcribe_greedy(pcm, prompt, NEW)
+        assert got.shape == (8, NEW) and np.all(lens == NEW)
+        # structure (whisper/decoding.py ApplyTimestampRules)
+        assert np.all(got[:, 0] >= TS) and np.all(got[:, 0] <= TS + MAXI), got[:, 0]
+        assert got.max() < V and not (set(got.ravel().tolist()) & set(suppress))
+        for b in range(8):
+            ts = [t for t in got[b] if t >= TS]
+            assert all(x <= y for x, y in zip(ts, ts[1:])), (b, ts)
+            isT = [t >= TS for t in got[b]]
+            assert not any(isT[i] and isT[i + 1] and isT[i + 2] for i in range(NEW - 2)), (b, got[b])
+        xa = ctx.encode_mel(mel)
+        # the values first: teacher-forced logits of the GPU vs the oracle on this model (the stated relative tolerance)
+        seq0 = np.concatenate([prompt, got[0]])[None, :8].astype(np.int32)
+        e_log = R.rel_l2(ctx.decode_logits(seq0, xa[:1]), R.decode_logits(sd, dims, seq0, xa[:1]).numpy())
+        assert e_log <= LOGIT_TOL, e_log
+        n_forced, n_near = _check_policy_choices(sd, dims, xa, prompt, got, suppress, [220, EOT], TS, EOT, MAXI)
+        n_text = int((got < TS).sum())
+        print("%s production vocabulary: %d text / %d timestamp tokens, %d forced by the sum rule, %d near-ties, "
+              "teacher-forced logits rel-L2 %.2e" % (model, n_text, got.size - n_text, n_forced, n_near, e_log))
+        assert n_text > 0 and (got[:, 1:] >= TS).any()          # both branches of the rules are exercised
+        # decode groups of 17 rows (two batch blocks, one arg-max workgroup per 16 rows) and of 40 (three blocks, the wide
+        # logits launch): a call of 51 / 120 chunks runs as three balanced groups on the lanes
+        for n in ((51, 120) if model == "large-v2" else (51,)):
+            idx = [(3 * i + 1) % 8 for i in range(n)]
+            many, ml = ctx.transcribe_greedy(pcm[idx], prompt, NEW)
+            assert np.array_equal(many, got[idx]) and np.all(ml == NEW), n
+    finally:
+        ctx.set_timestamp_rules(False)
+        ctx.set_suppress([], [])
+    free, _ = ctx.transcribe_greedy(pcm[:2], prompt, 6)          # filters off again: text may open the transcript
+    _check_greedy_against_teacher_forced_oracle(sd, dims, xa[:2], prompt, free, scaled=True)
+    ctx.close()
+
+
+@pytest.mark.parametrize("model,d,heads", [("small", 768, 12), ("medium", 1024, 16)])
+def test_decode_groups_above_sixteen_at_d768_and_d1024(pkg, model, d, heads):
+    """at d = 768 (whisper-small, the reference's model) and d = 1024 the fc2 product splits K over
+    16 waves; with more than 16 rows its launch shape was rejected (WM_ERR_INVALID on every decode step).  One decode step
+    at 17 / 32 rows (wm_detect_language) and KV-cached greedy in groups of 17 / 18 (a 52-chunk call over three lanes)
+    against the same chunks decoded in a group of 7, plus the oracle on the small group."""
+    import torch
+    dims = dict(pkg.binding.MODEL_DIMS["small"], n_audio_state=d, n_audio_head=heads, n_text_state=d, n_text_head=heads,
+                n_audio_layer=2, n_text_layer=2)
+    ctx = pkg.binding.Context(dims)
+    ctx.init_synthetic(31)
+    _perturb_ln_on_device(ctx, dims, seed=2)
+    _lively_on_device(ctx, dims)
+    ctx.finalize()
+    sd = _oracle_weights(ctx, dims)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    base = tones(7)
+    mel = ctx.logmel(base, out_dtype=np.float32)
+    xa = ctx.encode_mel(mel)
+    one = ctx.detect_language(xa)
+    _, conf = R.detect_language(sd, dims, xa)
+    for b in range(7):
+        _check_choice(conf[b], int(one[b]))
+    for Bn in (17, 32):
+        idx = [(3 * i + 2) % 7 for i in range(Bn)]
+        assert np.array_equal(ctx.detect_language(xa[idx]), one[idx]), Bn
+    prompt = [50258, 50259, 50359, 50363]
+    want, _ = ctx.transcribe_greedy(base, prompt, 8)
+    _check_greedy_against_teacher_forced_oracle(sd, dims, xa, prompt, want, scaled=True)
+    idx = [(5 * i + 1) % 7 for i in range(52)]                   # 3 lanes -> groups of 18 / 17 / 17
+    got, lens = ctx.transcribe_greedy(base[idx], prompt, 8)
+    assert np.array_equal(got, want[idx]) and np.all(lens == 8)
+    ctx.close()
+
+
+def _truncate_like_the_host(full, eot, budgets=None):
+    """What decoding every position and truncating on the host gives (the round-2 behaviour, and the definition of the
+    result): length = first eot + 1, capped by the chunk's budget; padding = eot."""
+    Bn, n = full.shape
+    toks = np.full((Bn, n), eot, np.int32)
+    lens = np.zeros(Bn, np.int32)
+    for b in range(Bn):
+        ln = n if budgets is None else min(n, int(budgets[b]))
+        hit = np.nonzero(full[b, :ln] == eot)[0] if eot >= 0 else np.zeros(0, int)
+        if hit.size:
+            ln = int(hit[0]) + 1
+        toks[b, :ln] = full[b, :ln]
+        lens[b] = ln
+    return toks, lens
+
+
+def test_early_stop_equals_truncation_and_cuts_the_work(lively, pkg):
+    """a sequence that has emitted <|endoftext|> (or used up its token budget) leaves the decode -- its
+    rows drop out of the attention pair walk, and a group whose rows have all stopped is not decoded any further (the host
+    polls a device-side live count between bursts of positions).  Tokens and lengths must be exactly what decoding every
+    position and truncating gives; groups of 1 / 7 / 19 (three lanes) / 120 (three groups of 40: three arg-max workgroups,
+    cross-workgroup live-list rebuild) rows."""
+    dims, _, _, ctx = lively
+    base = tones(7)
+    prompt = [10, 21, 5]
+    NEW = 40
+    full7, _ = ctx.transcribe_greedy(base, prompt, NEW, eot=-1)
+    vals, counts = np.unique(full7[:, 2:], return_counts=True)
+    rng = np.random.default_rng(4)
+    for n in (1, 7, 19, 120):
+        idx = [(5 * i + 3) % 7 for i in range(n)]
+        full = full7[idx]
+        # stop tokens that occur at different positions in different rows (and one that never occurs)
+        cands = [int(v) for v in vals[np.argsort(-counts)][:3]] + [int(full7[0, 9]), 1023]
+        for eot in cands:
+            want_t, want_l = _truncate_like_the_host(full, eot)
+            got_t, got_l = ctx.transcribe_greedy(base[idx], prompt, NEW, eot=eot)
+            assert np.array_equal(got_l, want_l), (n, eot, got_l, want_l)
+            assert np.array_equal(got_t, want_t), (n, eot)
+        budgets = rng.integers(1, NEW + 8, size=n)          # some above max_new: clamped
+        want_t, want_l = _truncate_like_the_host(full, -1, np.minimum(budgets, NEW))
+        got_t, got_l = ctx.transcribe_greedy(base[idx], prompt, NEW, eot=-1, budgets=budgets)
+        assert np.array_equal(got_l, want_l) and np.array_equal(got_t, want_t), n
+        eot = cands[0]                                       # both at once
+        want_t, want_l = _truncate_like_the_host(full, eot, np.minimum(budgets, NEW))
+        got_t, got_l = ctx.transcribe_greedy(base[idx], prompt, NEW, eot=eot, budgets=budgets)
+        assert np.array_equal(got_l, want_l) and np.array_equal(got_t, want_t), n
+    # budgets are consumed by one call and must match its B
+    again, _ = ctx.transcribe_greedy(base, prompt, NEW, eot=-1)
+    assert np.array_equal(again, full7)
+    ctx.set_token_budgets([3, 3])
+    with pytest.raises(pkg.binding.WhisperError, match="budgets"):
+        ctx.transcribe_greedy(base, prompt, NEW)
+    with pytest.raises(pkg.binding.WhisperError, match="< 1"):
+        ctx.set_token_budgets([0])
+    # timestamp rules + suppress lists + early stop together (the rule state of a finished row is simply not used)
+    TS, EOT = 900, 890
+    ctx.set_suppress(list(range(EOT + 1, TS)), [EOT])
+    ctx.set_timestamp_rules(True, TS, EOT, 20)
+    try:
+        f2, _ = ctx.transcribe_greedy(base, prompt, NEW, eot=-1)
+        for eot in (EOT, int(f2[1, 5])):
+            want_t, want_l = _truncate_like_the_host(f2, eot)
+            got_t, got_l = ctx.transcribe_greedy(base, prompt, NEW, eot=eot)
+            assert np.array_equal(got_l, want_l) and np.array_equal(got_t, want_t), eot
+    finally:
+        ctx.set_timestamp_rules(False)
+        ctx.set_suppress([], [])
+
+
+def test_early_stop_decode_time_follows_the_longest_live_sequence(pkg):
+    """Decode time must scale with the positions actually needed: at large-v2 width (4 layers), 24 chunks, 200 new tokens,
+    (a) every chunk stopping after 20 tokens costs a fraction of the full decode, (b) ONE straggler keeps the group alive
+    to the end but the 23 finished rows no longer stream their cross-attention caches."""
+    dims = dict(pkg.binding.MODEL_DIMS["large-v2"], n_audio_layer=2, n_text_layer=4)
+    ctx = pkg.binding.Context(dims)
+    ctx.init_synthetic(5)
+    ctx.finalize()
+    n, NEW = 24, 200
+    pcm = np.stack([L.synth_chunk(i % 3) for i in range(n)]).astype(np.float32)
+    prompt = [50258, 50259, 50359, 50363]
+    dp = ctx.to_device(np.round(pcm * 32767).astype(np.int16))
+
+    def run(budgets):
+        best = None
+        for _ in range(2):
+            toks, lens = ctx.transcribe_greedy(dp, prompt, NEW, eot=-1, mem=pkg.binding.WM_MEM_DEVICE,
+                                               pcm_dtype=pkg.binding.WM_I16, B=n, budgets=budgets)
+            ms = float(ctx.last_stage_ms()[2])
+            best = ms if best is None else min(best, ms)
+        return best, toks, lens
+
+    t_full, full, _ = run(None)
+    t_short, short, l_short = run([20] * n)
+    t_strag, strag, l_strag = run([20] * (n - 1) + [NEW])
+    print("decode ms: full %.1f, all stop at 20: %.1f, one straggler: %.1f" % (t_full, t_short, t_strag))
+    assert np.all(l_short == 20) and np.array_equal(short[:, :20], full[:, :20])
+    assert l_strag.tolist() == [20] * (n - 1) + [NEW] and np.array_equal(strag[-1], full[-1])
+    assert t_short <= 0.25 * t_full, (t_short, t_full)          # 23 positions (+ <= 2 bursts of slack) instead of 203
+    assert t_strag <= 0.80 * t_full, (t_strag, t_full)          # weights still stream, 23 of 24 cache streams do not
+    ctx.dev_free(dp)
+    ctx.close()
