@@ -32,15 +32,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
-    const float2 *xr = (const float2 *)(x + (size_t)row * d);
-    const int np = d >> 1;  // float2 pairs per row
-    float2 v[MAXP];
+    // 16 bytes per lane per load (one 1 KiB request per wave-instruction), all MAXP loads of the row in flight at once
+    const float4 *xr = (const float4 *)(x + (size_t)row * d);
+    const int np = d >> 2;  // float4 quads per row (d % 4 == 0, checked by the launcher)
+    float4 v[MAXP];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
         const int idx = i * 64 + lane;
-        v[i] = (idx < np) ? xr[idx] : make_float2(0.f, 0.f);
-        s += v[i].x + v[i].y;
+        v[i] = (idx < np) ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -50,23 +51,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     for (int i = 0; i < MAXP; ++i) {
         const int idx = i * 64 + lane;
         if (idx < np) {
-            const float a = v[i].x - mean, c = v[i].y - mean;
-            q += a * a + c * c;
+            const float a = v[i].x - mean, c = v[i].y - mean, e = v[i].z - mean, f = v[i].w - mean;
+            q += (a * a + c * c) + (e * e + f * f);
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float rstd = rsqrtf(q / (float)d + 1e-5f);
-    const float2 *g2 = (const float2 *)g, *b2 = (const float2 *)b;
+    const float4 *g4 = (const float4 *)g, *b4 = (const float4 *)b;
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
         const int idx = i * 64 + lane;
         if (idx < np) {
-            const float2 gg = g2[idx], bb = b2[idx];
+            const float4 gg = g4[idx], bb = b4[idx];
             const float y0 = (v[i].x - mean) * rstd * gg.x + bb.x;
             const float y1 = (v[i].y - mean) * rstd * gg.y + bb.y;
-            if (ob) ((unsigned *)(ob + (size_t)row * d))[idx] = pack2(y0, y1);
-            if (of) ((float2 *)(of + (size_t)row * d))[idx] = make_float2(y0, y1);
+            const float y2 = (v[i].z - mean) * rstd * gg.z + bb.z;
+            const float y3 = (v[i].w - mean) * rstd * gg.w + bb.w;
+            if (ob) ((uint2 *)(ob + (size_t)row * d))[idx] = make_uint2(pack2(y0, y1), pack2(y2, y3));
+            if (of) ((float4 *)(of + (size_t)row * d))[idx] = make_float4(y0, y1, y2, y3);
         }
     }
 }
@@ -294,15 +297,15 @@ __global__ __launch_bounds__(256, 4) void enc_attn_kernel(const bf16_t *__restri
 
 int wm_layernorm(wm_ctx *ctx, const float *x, const float *g, const float *b, int rows, int d,
                  bf16_t *out_bf16, float *out_f32) {
-    WM_REQUIRE(d % 2 == 0 && d <= 1280, WM_ERR_INVALID, "layernorm: d=%d unsupported (even, <= 1280)", d);
+    WM_REQUIRE(d % 4 == 0 && d <= 1280, WM_ERR_INVALID, "layernorm: d=%d unsupported (a multiple of 4, <= 1280)", d);
     WmProfScope ps(&ctx->prof, "layernorm", ctx->stream);
     const int grid = (rows + 3) / 4;
     if (d <= 256)
-        layernorm_kernel<2><<<grid, 256, 0, ctx->stream>>>(x, g, b, rows, d, out_bf16, out_f32);
+        layernorm_kernel<1><<<grid, 256, 0, ctx->stream>>>(x, g, b, rows, d, out_bf16, out_f32);
     else if (d <= 768)
-        layernorm_kernel<6><<<grid, 256, 0, ctx->stream>>>(x, g, b, rows, d, out_bf16, out_f32);
+        layernorm_kernel<3><<<grid, 256, 0, ctx->stream>>>(x, g, b, rows, d, out_bf16, out_f32);
     else
-        layernorm_kernel<10><<<grid, 256, 0, ctx->stream>>>(x, g, b, rows, d, out_bf16, out_f32);
+        layernorm_kernel<5><<<grid, 256, 0, ctx->stream>>>(x, g, b, rows, d, out_bf16, out_f32);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Turn "parity unpinned" into "pinned" -- run this ONCE on a machine that has what this image lacks.
+
+The reference (tanmayb123/OpenAI-Whisper-CoreML) holds no tests and no golden outputs, and neither of its two native
+halves can be executed in the build container: the Rust `stft` crate needs cargo + its un-vendored crates (realfft 3.0.1,
+rustfft 6.0.1, npy, num, lazy_static -- stft/Cargo.lock), the model half needs the `openai-whisper` package and the
+"small" checkpoint that whisper_to_cml.py:7 downloads.  Every parity test therefore compares the HIP path with this
+repo's own restatements (oracle/).  This script records the REFERENCE's outputs for the seeded inputs the tests already
+use, as small fixtures under tests/golden/; tests/test_reference_goldens.py picks them up automatically (it is skipped
+while they do not exist) and pins the oracle -- and through it the HIP path -- to the reference itself.
+
+    # front end (needs cargo and network access for the crates):
+    python tests/golden/dump_reference_goldens.py --stft-crate /path/to/OpenAI-Whisper-CoreML/stft
+    # model (needs `pip install openai-whisper`; downloads "small" exactly as whisper_to_cml.py:7 does):
+    python tests/golden/dump_reference_goldens.py --whisper-model small
+
+Nothing here is product code, and nothing of the reference's sources is copied: the crate is built where it lies (as a
+cdylib, through an out-of-tree CARGO_TARGET_DIR and a --crate-type override on the command line) and called through the
+very symbol the Swift app calls (bridge.h:11); the model is driven through openai-whisper's public API.
+"""
+import argparse
+import ctypes
+import glob
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import logmel_np as L  # noqa: E402  (only for the seeded inputs: synth_chunk)
+
+FRAMES_SEED = 7   # same sampled frames as make_golden.py
+
+
+def sampled_frames():
+    rng = np.random.default_rng(FRAMES_SEED)
+    return np.sort(np.concatenate([[0, 1, 2, 2997, 2998, 2999], rng.choice(np.arange(3, 2997), 58, replace=False)]))
+
+
+def dump_stft(crate_dir):
+    """cargo rustc --release --crate-type cdylib in the reference crate, then generate_spectrogram(audio, output) --
+    stft/src/lib.rs:110-122 -- on the seeded chunks, with stft.swift:10-12's buffer conventions."""
+    target = tempfile.mkdtemp(prefix="stft_target_")
+    env = dict(os.environ, CARGO_TARGET_DIR=target)
+    subprocess.run(["cargo", "rustc", "--release", "--lib", "--crate-type", "cdylib"], cwd=crate_dir, env=env, check=True)
+    so = glob.glob(os.path.join(target, "release", "libstft.*"))
+    so = [p for p in so if p.endswith((".so", ".dylib"))]
+    assert so, "cargo produced no cdylib under %s" % target
+    lib = ctypes.CDLL(so[0])
+    lib.generate_spectrogram.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.generate_spectrogram.restype = None
+    frames = sampled_frames()
+    out = {"frames": frames, "source": np.array("rust stft crate, cargo release build, realfft per Cargo.lock")}
+    cases = {"noise0": L.synth_chunk(0), "noise1": L.synth_chunk(1), "zeros": np.zeros(480000, np.float32),
+             "ones": np.ones(480000, np.float32)}
+    for name, x in cases.items():
+        buf = np.zeros(480400, np.float64)                    # stft.swift:10-11: 200 zeros each side
+        buf[200:480200] = x.astype(np.float64)                # ContentView.swift:59: Float -> Double
+        res = np.zeros(240000, np.float64)                    # stft.swift:12
+        lib.generate_spectrogram(buf.ctypes.data_as(ctypes.c_void_p), res.ctypes.data_as(ctypes.c_void_p))
+        y = res.reshape(80, 3000)
+        out[name + "_cols"] = y[:, frames]
+        out[name + "_sum"] = np.array([y.sum(), np.abs(y).sum(), (y * y).sum(), y.max(), y.min()])
+        out[name + "_pad_head"] = buf[:200].copy()            # lib.rs:34-40 mutates the caller's buffer
+        out[name + "_pad_tail"] = buf[480200:].copy()
+    path = os.path.join(HERE, "ref_stft_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path)
+
+
+def dump_whisper(name):
+    """whisper.load_model(name) on CPU in fp32 -- whisper_to_cml.py:6-8 -- then the two traced graphs on a seeded input:
+    encoder (1,80,3000) -> (1,1500,d) (:10-23) and decoder tokens (1,T) + audio features -> logits (:25-43)."""
+    import torch
+    import whisper
+    model = whisper.load_model(name).cpu().float().eval()
+    dims = {k: int(v) for k, v in vars(model.dims).items()}
+    sd = model.state_dict()
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].cpu().float().numpy().tobytes())
+    x = L.synth_chunk(0)
+    mel = whisper.log_mel_spectrogram(torch.from_numpy(x))[None]            # whisper's own front end: (1, n_mels, 3000)
+    with torch.no_grad():
+        xa = model.encoder(mel)
+        sot = 50258 if dims["n_vocab"] >= 51865 else 50257
+        toks = torch.tensor([[sot, sot + 1, sot + 101, sot + 105]]) if dims["n_vocab"] >= 51865 else torch.tensor([[50257, 50362]])
+        logits = model.decoder(toks, xa)
+    rows = np.array([0, 1, 2, 3, 100, 500, 749, 750, 1000, 1496, 1497, 1498, 1499])
+    out = {"model": np.array(name), "dims_keys": np.array(sorted(dims)), "dims_vals": np.array([dims[k] for k in sorted(dims)]),
+           "state_sha256": np.array(h.hexdigest()), "mel": mel[0].numpy().astype(np.float32), "rows": rows,
+           "xa_rows": xa[0, rows].numpy(), "xa_sum": np.array([float(xa.sum()), float(xa.abs().sum())]),
+           "tokens": toks.numpy().astype(np.int32), "logits_lang": logits[0, 0, 50259:50358].numpy() if dims["n_vocab"] >= 51865 else np.zeros(0),
+           "logits_head": logits[0, :, :256].numpy(), "logits_argmax": logits[0].argmax(-1).numpy(),
+           "logits_sum": np.array([float(logits.sum()), float(logits.abs().sum())])}
+    path = os.path.join(HERE, "ref_whisper_%s_golden.npz" % name.replace(".", "_"))
+    np.savez_compressed(path, **out)
+    print("wrote", path, "-- convert the same checkpoint with openai-whisper-coreml_amd/weights.py:convert_openai_pt and set "
+          "WM_REF_WEIGHTS=<flat file> so that tests/test_reference_goldens.py can load it")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stft-crate", help="path to the reference's stft/ crate directory")
+    ap.add_argument("--whisper-model", help='openai-whisper model name, e.g. "small" (whisper_to_cml.py:7)')
+    a = ap.parse_args()
+    if not a.stft_crate and not a.whisper_model:
+        ap.error("nothing to do: give --stft-crate and / or --whisper-model")
+    if a.stft_crate:
+        dump_stft(a.stft_crate)
+    if a.whisper_model:
+        dump_whisper(a.whisper_model)

@@ -1,0 +1,91 @@
+"""Reference-held golden vectors (tests/golden/ref_*.npz), produced by tests/golden/dump_reference_goldens.py on a machine
+that can run the reference itself (cargo for the Rust stft crate; openai-whisper + the "small" checkpoint for the model).
+They do not exist in this image -- every test here SKIPS until someone commits them -- and when they do, they pin the
+oracle (and through the existing parity tests, the HIP path) to the reference's own outputs: the one thing that lifts
+the "parity unpinned" cap.  CPU tests pin the oracle; the GPU tests pin the HIP path directly."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, oracle_logmel
+from oracle import logmel_np as L
+
+STFT = os.path.join(GOLDEN, "ref_stft_golden.npz")
+WHISPER = sorted(glob.glob(os.path.join(GOLDEN, "ref_whisper_*_golden.npz")))
+
+
+def _cases(g):
+    return {"noise0": L.synth_chunk(0), "noise1": L.synth_chunk(1), "zeros": np.zeros(480000, np.float32),
+            "ones": np.ones(480000, np.float32)}
+
+
+@pytest.mark.skipif(not os.path.exists(STFT), reason="no reference-held front-end vectors (run tests/golden/dump_reference_goldens.py --stft-crate where cargo exists)")
+def test_oracle_front_end_equals_the_rust_crate(oracle_lib):
+    g = np.load(STFT)
+    for name, x in _cases(g).items():
+        y, buf = oracle_logmel(oracle_lib, x)
+        assert np.array_equal(buf[:200], g[name + "_pad_head"]) and np.array_equal(buf[480200:], g[name + "_pad_tail"])   # lib.rs:34-40, integer-exact
+        assert np.abs(y[:, g["frames"]] - g[name + "_cols"]).max() <= 1e-9, name      # realfft vs this FFT: f64 round-off only
+        assert abs(y.sum() - g[name + "_sum"][0]) <= 1e-5 and abs(y.max() - g[name + "_sum"][3]) <= 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(STFT), reason="no reference-held front-end vectors")
+def test_hip_front_end_equals_the_rust_crate(pkg):
+    g = np.load(STFT)
+    for name, x in _cases(g).items():
+        y = pkg.generateSpectrogram(x.astype(np.float64)).reshape(80, 3000)
+        assert np.abs(y[:, g["frames"]] - g[name + "_cols"]).max() <= 1e-9, name
+
+
+def _load_model_fixture(path):
+    g = np.load(path)
+    dims = {str(k): int(v) for k, v in zip(g["dims_keys"], g["dims_vals"])}
+    return g, dims
+
+
+@pytest.mark.parametrize("path", WHISPER or [None])
+def test_oracle_model_equals_openai_whisper(path):
+    if path is None:
+        pytest.skip("no reference-held model vectors (run tests/golden/dump_reference_goldens.py --whisper-model small)")
+    wts = os.environ.get("WM_REF_WEIGHTS")
+    if not wts or not os.path.exists(wts):
+        pytest.skip("set WM_REF_WEIGHTS to the flat weight file converted from the same checkpoint")
+    import importlib
+    from oracle import whisper_ref as R
+    W = importlib.import_module("openai_whisper_coreml_amd.weights")
+    g, dims = _load_model_fixture(path)
+    d2, sd = W.load_flat(wts)
+    assert d2 == dims
+    sd = R.to_torch(sd)
+    xa = R.encode(sd, dims, g["mel"][None]).numpy()
+    assert R.rel_l2(xa[0, g["rows"]], g["xa_rows"]) <= 1e-4          # fp32 vs fp32: the same arithmetic, different kernels
+    lg = R.decode_logits(sd, dims, g["tokens"], xa).numpy()
+    assert R.rel_l2(lg[0, :, :256], g["logits_head"]) <= 1e-4
+    assert np.array_equal(lg[0].argmax(-1), g["logits_argmax"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", WHISPER or [None])
+def test_hip_model_equals_openai_whisper(pkg, path):
+    if path is None:
+        pytest.skip("no reference-held model vectors")
+    wts = os.environ.get("WM_REF_WEIGHTS")
+    if not wts or not os.path.exists(wts):
+        pytest.skip("set WM_REF_WEIGHTS to the flat weight file converted from the same checkpoint")
+    from oracle import whisper_ref as R
+    g, dims = _load_model_fixture(path)
+    ctx = pkg.binding.Context(dims)
+    ctx.load_weights(wts)
+    ctx.finalize()
+    xa = ctx.encode_mel(g["mel"][None])
+    assert R.rel_l2(xa[0, g["rows"]], g["xa_rows"]) <= 5e-3          # the stated encoder tolerance (bf16 operands)
+    lg = ctx.decode_logits(g["tokens"], xa)
+    assert R.rel_l2(lg[0, :, :256], g["logits_head"]) <= 1e-2        # the stated logits tolerance
+    if g["logits_lang"].size:                                        # Whisper.swift:37-38: the language arg-max
+        lang = ctx.detect_language(xa)
+        ref = g["logits_lang"]
+        assert ref.max() - ref[int(lang[0])] <= 0.05
+    ctx.close()
