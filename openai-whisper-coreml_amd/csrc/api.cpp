@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -299,32 +300,63 @@ extern "C" int wm_logmel(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int n
     return WM_OK;
 } WM_API_CATCH
 
-// The reference's symbol (bridge.h:11 / lib.rs:110-122).  One lazily created context per
-// process, serialised by a mutex so the symbol stays re-entrant like the reference's.
-static std::mutex g_gs_mutex;
-static wm_ctx *g_gs_ctx = nullptr;
+// The reference's symbol (bridge.h:11 / lib.rs:110-122).  The Rust crate's entry is re-entrant (immutable lazily
+// initialised state, lib.rs:11-14), so concurrent callers must not queue behind one another here either: a small pool of
+// lazily created front-end contexts (own stream, tables and staging each), handed out under a mutex and used outside it.
+namespace {
+constexpr int kGsMaxContexts = 8;
+std::mutex g_gs_mutex;
+std::condition_variable g_gs_cv;
+std::vector<wm_ctx *> g_gs_free;
+int g_gs_created = 0;
 
-extern "C" void generate_spectrogram(double *audio, double *output) {
-    std::lock_guard<std::mutex> lock(g_gs_mutex);
-    if (!g_gs_ctx) {
-        const char *dev = getenv("WM_DEVICE");
-        int st = wm_create_frontend(dev ? atoi(dev) : 0, &g_gs_ctx);
-        if (st != WM_OK) {
-            fprintf(stderr, "generate_spectrogram: no usable MI355X context (%s); there is no CPU fallback\n",
-                    wm_last_error());
-            abort();  // the reference panics (=abort across FFI) on its internal failures too
+wm_ctx *gs_acquire() {
+    {
+        std::unique_lock<std::mutex> lock(g_gs_mutex);
+        for (;;) {
+            if (!g_gs_free.empty()) {
+                wm_ctx *c = g_gs_free.back();
+                g_gs_free.pop_back();
+                return c;
+            }
+            if (g_gs_created < kGsMaxContexts) {
+                ++g_gs_created;
+                break;  // create one outside the lock
+            }
+            g_gs_cv.wait(lock);
         }
     }
+    const char *dev = getenv("WM_DEVICE");
+    wm_ctx *c = nullptr;
+    if (wm_create_frontend(dev ? atoi(dev) : 0, &c) != WM_OK) {
+        fprintf(stderr, "generate_spectrogram: no usable MI355X context (%s); there is no CPU fallback\n", wm_last_error());
+        abort();  // the reference panics (=abort across FFI) on its internal failures too
+    }
+    return c;
+}
+
+void gs_release(wm_ctx *c) {
+    {
+        std::lock_guard<std::mutex> lock(g_gs_mutex);
+        g_gs_free.push_back(c);
+    }
+    g_gs_cv.notify_one();
+}
+}  // namespace
+
+extern "C" void generate_spectrogram(double *audio, double *output) {
     // lib.rs:34-40,113: the reflect pad is written into the CALLER's buffer (visible side effect).
     for (int i = 0; i < 200; ++i) {
         audio[i] = audio[400 - i];
         const int j = 16000 * 30 + i + 200;
         audio[j] = audio[200 + (16000 * 30 - 2) - i];
     }
+    wm_ctx *ctx = gs_acquire();
     // The device kernel re-derives the same pad by index arithmetic from samples [200, 480200).
-    int st = wm_logmel(g_gs_ctx, audio + 200, WM_F64, 1, 80, output, WM_F64, WM_MEM_HOST);
+    int st = wm_logmel(ctx, audio + 200, WM_F64, 1, 80, output, WM_F64, WM_MEM_HOST);
     if (st != WM_OK) {
         fprintf(stderr, "generate_spectrogram: %s\n", wm_last_error());
         abort();
     }
+    gs_release(ctx);
 }

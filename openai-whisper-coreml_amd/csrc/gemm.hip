@@ -240,8 +240,30 @@ __device__ __forceinline__ void resid_tile_staged(const GemmDev &p, const f32x4 
     const unsigned rpb = (unsigned)p.c_rpb;
     const unsigned q_last = (unsigned)(p.M - 1) / rpb, rem_last = (unsigned)(p.M - 1) - q_last * rpb;  // (uniform)
     const int rrow = lane >> 4, c4 = lane & 15;
+    constexpr int NP = MI / 2;  // passes of 32 rows
+    // The read-modify-write is load LATENCY (a dependent HBM round trip per pass): the eight 16-byte loads of a pass are
+    // requested together, AND one pass ahead -- the loads of pass ps + 1 are in flight while pass ps is transposed through
+    // LDS, added and stored (two register sets; the main loop's operand registers are dead by now).  Rows past M re-read
+    // row M - 1 and store nothing (selects, no branches: the loads of a pass must stay one batch).
+    float4 c[2][8];
+    auto request = [&](int ps, float4 (&cc)[8]) {
+        // row -> (batch, row-in-batch): one division per pass, then 4 rows further per step (rows-per-batch >= 8)
+        unsigned m = (unsigned)(mwave0 + ps * 32 + rrow);
+        unsigned q = m / rpb, rem = m - q * rpb;
 #pragma unroll
-    for (int ps = 0; ps < MI / 2; ++ps) {
+        for (int t = 0; t < 8; ++t) {
+            const bool ok = (int)m < p.M;
+            const unsigned mq = ok ? q : q_last, mr = ok ? rem : rem_last;
+            cc[t] = *(const float4 *)((const float *)p.C + (long)mq * p.c_bstride + (long)mr * p.c_rstride + nwave0 + c4 * 4);
+            m += 4;
+            rem += 4;
+            if (rem >= rpb) { rem -= rpb; ++q; }
+        }
+    };
+    request(0, c[0]);
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+        if (ps + 1 < NP) request(ps + 1, c[(ps + 1) & 1]);
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -250,33 +272,20 @@ __device__ __forceinline__ void resid_tile_staged(const GemmDev &p, const f32x4 
                 for (int r = 0; r < 4; ++r)
                     *(float *)(L + (ii * 16 + fq * 4 + r) * STAGE_F32_ROW_BYTES + (j * 16 + frow) * 4) =
                         acc[ps * 2 + ii][j][r] + bv[j];
-        // the read-modify-write is load LATENCY: all eight rows of the pass are requested before the first one is added
-        // and stored (one HBM round trip per pass instead of eight load -> add -> store chains; the compiler cannot hoist
-        // the loads over the stores itself: they may alias).  Rows past M re-read row M - 1 and store nothing.
-        float4 *dst[8];
-        float4 c[8];
-        // row -> (batch, row-in-batch): one division per pass, then 4 rows further per step (rows-per-batch >= 8); rows
-        // past M re-read row M - 1 (selects, no branches: the eight loads must stay one batch)
         unsigned m = (unsigned)(mwave0 + ps * 32 + rrow);
         unsigned q = m / rpb, rem = m - q * rpb;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const bool ok = (int)m < p.M;
-            const unsigned mq = ok ? q : q_last, mr = ok ? rem : rem_last;
-            dst[t] = (float4 *)((float *)p.C + (long)mq * p.c_bstride + (long)mr * p.c_rstride + nwave0 + c4 * 4);
-            c[t] = *dst[t];
+            const int row = t * 4 + rrow;
+            const float4 v = *(const float4 *)(L + row * STAGE_F32_ROW_BYTES + c4 * 16);
+            if ((int)m < p.M) {
+                float4 r = c[ps & 1][t];
+                r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+                *(float4 *)((float *)p.C + (long)q * p.c_bstride + (long)rem * p.c_rstride + nwave0 + c4 * 4) = r;
+            }
             m += 4;
             rem += 4;
             if (rem >= rpb) { rem -= rpb; ++q; }
-        }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int row = t * 4 + rrow;
-            const float4 v = *(const float4 *)(L + row * STAGE_F32_ROW_BYTES + c4 * 16);
-            if (mwave0 + ps * 32 + row >= p.M) continue;
-            float4 r = c[t];
-            r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
-            *dst[t] = r;
         }
     }
 }
