@@ -223,11 +223,18 @@ def main():
     dist = None
     torch = None
     use_dist = world > 1 or os.environ.get("WM_BENCH_FORCE_DIST") == "1"
+    # WM_BENCH_DIST_BACKEND=gloo: the same N-rank code path with the collectives on the host -- lets a ONE-GPU box run two
+    # ranks that share device 0 (RCCL refuses two ranks on one device); the driver's runs use the default, nccl == RCCL.
+    dist_backend = os.environ.get("WM_BENCH_DIST_BACKEND", "nccl")
+    dist_dev = "cuda" if dist_backend == "nccl" else None
     if use_dist:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        if dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend=dist_backend)
 
     # this harness supplies the concurrency itself (S host threads x one decode group each): one lane per call
     os.environ.setdefault("WM_LANES", "1")
@@ -236,7 +243,8 @@ def main():
     B = pkg.binding
     sharding = importlib.import_module("openai_whisper_coreml_amd.sharding")
     dims = B.MODEL_DIMS[args.model]
-    ctx = B.Context(dims, device=local_rank)
+    # WM_BENCH_LOCAL_DEVICE: device ordinal override (two ranks sharing one GPU in the one-GPU-box test)
+    ctx = B.Context(dims, device=int(os.environ.get("WM_BENCH_LOCAL_DEVICE", local_rank)))
     ctx.init_synthetic(20240928)
     ctx.finalize()
 
@@ -295,7 +303,7 @@ def main():
             return toks, lens
 
         _, g = sharding.run_grouped(plan, S, run_group, nb, max_new, dist=dist if (use_dist and collective) else None,
-                                    world_size=world, device="cuda" if use_dist else None)
+                                    world_size=world, device=dist_dev if use_dist else None)
         if g is not None:
             gathered = g
         return stage_sum
@@ -303,7 +311,8 @@ def main():
     def sync_all():
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize()
+            if dist_dev:
+                torch.cuda.synchronize()
         for c in ctxs:
             c.sync()
 
@@ -320,7 +329,8 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64).cuda()
+        tt = torch.tensor([dt], dtype=torch.float64)
+        tt = tt.cuda() if dist_dev else tt
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -351,7 +361,8 @@ def main():
         sync_all()
         dt_e = time.perf_counter() - t_e0
         if use_dist:
-            te = torch.tensor([dt_e], dtype=torch.float64).cuda()
+            te = torch.tensor([dt_e], dtype=torch.float64)
+            te = te.cuda() if dist_dev else te
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
             dt_e = float(te.item())
         early = {"value": 30.0 * nb * world * args.steps / dt_e, "unit": "audio-sec/s", "ms_per_step": dt_e / args.steps * 1e3,

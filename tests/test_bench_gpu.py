@@ -87,3 +87,28 @@ dist.destroy_process_group()
     assert r.returncode == 0, r.stderr[-3000:]
     tag = [l for l in r.stdout.splitlines() if l.startswith("RCCL_LIBS")]
     assert tag and tag[0].split()[1] == "1", r.stdout[-2000:]
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """The N > 1 path with N = 2 REAL ranks on this one-GPU box: two processes (torch.distributed.run), both on device 0,
+    each owning its own chunks, the token streams exchanged by the fixed-stride all-gather, MAX over ranks, rank 0 prints
+    the line.  RCCL refuses two ranks on one device, so the collectives run over gloo (WM_BENCH_DIST_BACKEND) -- every
+    line of bench.py's distributed branch except the backend name is the code the 8-GPU run executes."""
+    env = dict(os.environ, WM_BENCH_DIST_BACKEND="gloo", WM_BENCH_NO_INSITU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--model", "base", "--new-tokens", "16", "--no-cpu-baseline", "--no-early-stop"]
+    # both ranks must land on GPU 0: torch.distributed.run sets LOCAL_RANK = 0 / 1; the box has one device
+    env["HIP_VISIBLE_DEVICES"] = "0"
+    env["WM_BENCH_LOCAL_DEVICE"] = "0"
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # ONE line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["tokens_consistent_across_groups"] is True
+    assert line["config"]["parallelism"] == "chunk-dp2"
+    assert line["value"] > 0 and abs(line["value"] - 30.0 * 8 * 2 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
