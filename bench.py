@@ -155,30 +155,41 @@ def cpu_baseline(ctx, dims, pcm16_chunk, prompt):
     # so this extrapolation is slightly pessimistic for the CPU
     t_step = max(t_dec - t_x, 1e-9) / n_steps / nl * dims["n_text_layer"]
     total = t_fe + t_enc + t_xkv + 224 * t_step
-    # tiny.en in full: timing does not depend on the weight values -> N(0, 0.02^2) drawn here
-    tiny = None
-    try:
-        import openai_whisper_coreml_amd as pkg
-        td = pkg.binding.MODEL_DIMS["tiny.en"]
-        g = torch.Generator().manual_seed(1)
-        tsd = {}
-        for n, shp, kind in W.tensor_specs(td):
-            if kind == W.K_LN_W:
-                tsd[n] = torch.ones(shp)
-            elif kind == W.K_LN_B:
-                tsd[n] = torch.zeros(shp)
-            else:
-                tsd[n] = torch.randn(shp, generator=g) * 0.02
-        tmel = out.astype(np.float32)
+    # tiny.en and base in full (SURVEY.md 8d / BASELINE.md): timing does not depend on the weight values -> N(0, 0.02^2) drawn here
+    def small_model_in_full(name, reps):
+        try:
+            import openai_whisper_coreml_amd as pkg
+            td = pkg.binding.MODEL_DIMS[name]
+            g = torch.Generator().manual_seed(1)
+            tsd = {}
+            for n, shp, kind in W.tensor_specs(td):
+                if kind == W.K_LN_W:
+                    tsd[n] = torch.ones(shp)
+                elif kind == W.K_LN_B:
+                    tsd[n] = torch.zeros(shp)
+                else:
+                    tsd[n] = torch.randn(shp, generator=g) * 0.02
+            tmel = out.astype(np.float32)
+            tprompt = [50257, 50362] if td["n_vocab"] < 51865 else list(prompt)
 
-        def tiny_full():
-            txa = R.encode(tsd, td, tmel)
-            R.greedy(tsd, td, txa, [50257, 50362], 224, eot=-1)
-        t_tiny, _ = _best_of(tiny_full, 2)
-        tiny = {"audio_s_per_s": 30.0 / (t_fe + t_tiny), "wall_s": t_fe + t_tiny,
-                "what": "tiny.en, 1 chunk, front end + encoder + 224-token KV-cached greedy, in full (min of 2)"}
-    except Exception as e:   # never take the large-v2 figure down
-        tiny = {"audio_s_per_s": None, "what": "failed: %r" % (e,)}
+            def full():
+                txa = R.encode(tsd, td, tmel)
+                R.greedy(tsd, td, txa, tprompt, 224, eot=-1)
+            t_m, _ = _best_of(full, reps)
+            return {"audio_s_per_s": 30.0 / (t_fe + t_m), "wall_s": t_fe + t_m,
+                    "what": "%s, 1 chunk, front end + encoder + 224-token KV-cached greedy, in full (min of %d)" % (name, reps)}
+        except Exception as e:   # never take the large-v2 figure down
+            return {"audio_s_per_s": None, "what": "failed: %r" % (e,)}
+    tiny = small_model_in_full("tiny.en", 2)
+    base = small_model_in_full("base", 1)
+    cpu_model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
     return {"value": 30.0 / total, "unit": "audio-sec/s", "cores": threads if cores >= threads else cores,
             "kind": "port",
             "sample": "1 chunk on %d host threads (%d usable cores), every timing the min of %d repetitions: C front-end "
@@ -190,7 +201,7 @@ def cpu_baseline(ctx, dims, pcm16_chunk, prompt):
             "decoder_tok_per_s": 1.0 / t_step,
             "frontend_audio_s_per_s_1_thread": 30.0 / t_fe,
             "frontend_audio_s_per_s_all_cores": (30.0 / t_fe_par) if t_fe_par else None,
-            "tiny_en_full": tiny}
+            "tiny_en_full": tiny, "base_full": base, "cpu_model": cpu_model, "nproc": os.cpu_count()}
 
 
 def main():
