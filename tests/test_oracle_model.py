@@ -6,6 +6,7 @@ import importlib
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import GOLDEN
@@ -212,3 +213,52 @@ def test_checkpoint_converters(tmp_path):
     W.convert_hf_safetensors(st, dims, out2)
     d2, s2 = W.load_flat(out2)
     assert d2 == dims and set(s2) == set(sd) and all(np.array_equal(s2[k], want[k]) for k in sd)
+
+
+def test_decode_policy_oracle_vs_transformers_logits_processors():
+    """The decode-policy half of the oracle (R.timestamp_filter + the suppress lists of R.greedy: openai-whisper's
+    ApplyTimestampRules / SuppressTokens / SuppressBlank, restated) against the INDEPENDENT implementation in transformers
+    (WhisperTimeStampLogitsProcessor, SuppressTokensLogitsProcessor, SuppressTokensAtBeginLogitsProcessor): same -inf mask
+    and same surviving logits at every step of random decodes -- histories produced by sampling from the filtered rows
+    themselves (so pairs, monotonic timestamps, the initial window and the summed-probability rule are all visited), at a
+    toy vocabulary and at large-v2's ids (timestamp_begin 50364 in a partial 16-column tile)."""
+    import types
+    import torch
+    tr = pytest.importorskip("transformers")
+    from transformers.generation.logits_process import (SuppressTokensAtBeginLogitsProcessor, SuppressTokensLogitsProcessor,
+                                                        WhisperTimeStampLogitsProcessor)
+    for V, TS, EOT, MAXI, steps, n_seq in ((600, 500, 480, 20, 40, 6), (51865, 50364, 50257, 50, 24, 3)):
+        rng = np.random.default_rng(V)
+        cfg = types.SimpleNamespace(no_timestamps_token_id=TS - 1, eos_token_id=EOT, bos_token_id=EOT,
+                                    max_initial_timestamp_index=MAXI)
+        prompt = [TS - 6, TS - 5, TS - 4]
+        hf_ts = WhisperTimeStampLogitsProcessor(cfg, begin_index=len(prompt))
+        suppress = sorted({int(t) for t in rng.integers(1, EOT, size=30)} | {TS - 1, TS - 2})
+        first = [3, EOT]
+        hf_sup = SuppressTokensLogitsProcessor(suppress)
+        hf_first = SuppressTokensAtBeginLogitsProcessor(first, begin_index=len(prompt))
+        n_forced = 0
+        for s in range(n_seq):
+            seq = []
+            for i in range(steps):
+                logits = torch.from_numpy(rng.standard_normal(V).astype(np.float32) * 2.0)
+                # bias the timestamps up now and then so that the summed-probability rule fires in both directions
+                if rng.random() < 0.5:
+                    logits[TS:] += float(rng.uniform(-4, 3))
+                ours = logits.clone()
+                ours[suppress] = float("-inf")
+                if i == 0:
+                    ours[first] = float("-inf")
+                forced, _ = R.timestamp_filter(ours, seq, TS, EOT, MAXI)
+                n_forced += forced
+                ids = torch.tensor([prompt + seq], dtype=torch.long)
+                theirs = hf_ts(ids, hf_first(ids, hf_sup(ids, logits[None].clone())))[0]
+                assert torch.equal(torch.isinf(ours), torch.isinf(theirs)), (V, s, i)
+                fin = ~torch.isinf(ours)
+                assert torch.equal(ours[fin], theirs[fin])
+                if fin.sum() == 0:
+                    break
+                seq.append(int(torch.argmax(ours)))
+            ts = [t for t in seq if t >= TS]
+            assert ts and all(a <= b for a, b in zip(ts, ts[1:])) and seq[0] >= TS and seq[0] <= TS + MAXI
+        assert n_forced > 0
