@@ -145,20 +145,23 @@ __global__ __launch_bounds__(256, 4) void enc_attn_kernel(const bf16_t *__restri
         for (int s4 = 0; s4 < 4; ++s4) qf[s4] = *(const bf16x8 *)(qp + 16 * s4);
     }
 
-    // tile staging: 512 16-byte chunks per operand; thread handles chunks tid and tid+256
-    const bf16_t *kbase = qk + (long)b * S * ld + d + h * 64;
-    const bf16_t *vbase = vt + (long)(b * H + h) * 64 * S_pad;
-    // staging registers (explicit scalars: keeps them out of scratch)
+    // tile staging: 512 16-byte chunks per operand; thread handles chunks tid and tid+256.  Addresses are a wave-uniform
+    // base (SGPRs) + a 32-bit per-thread byte offset (a chunk's K rows span < 8 MB): four 64-bit per-thread pointers and
+    // their 64-bit increments per tile cost 8-10 VGPRs at the 128-VGPR cap (the kernel used to spill 4).
+    const char *kbase = (const char *)(qk + (long)b * S * ld + d + h * 64);
+    const char *vbase = (const char *)(vt + (long)(b * H + h) * 64 * S_pad);
     const int row0 = tid >> 3, c8 = tid & 7, row1 = row0 + 32;
-    const bf16_t *kg0 = kbase + (long)row0 * ld + c8 * 8, *kg1 = kbase + (long)row1 * ld + c8 * 8;
-    const bf16_t *vg0 = vbase + (long)row0 * S_pad + c8 * 8, *vg1 = vbase + (long)row1 * S_pad + c8 * 8;
+    const unsigned kstep = (unsigned)(64 * ld * 2);            // bytes between consecutive 64-key tiles of K
+    const unsigned ko0 = (unsigned)(row0 * ld * 2 + c8 * 16), ko1 = (unsigned)(row1 * ld * 2 + c8 * 16);
+    const unsigned vo0 = (unsigned)(row0 * S_pad * 2 + c8 * 16), vo1 = (unsigned)(row1 * S_pad * 2 + c8 * 16);
     uint4 kr0, kr1, vr0, vr1;
-#define ATT_GLOAD(j)                                          \
-    do {                                                      \
-        kr0 = *(const uint4 *)(kg0 + (long)(j) * 64 * ld);    \
-        kr1 = *(const uint4 *)(kg1 + (long)(j) * 64 * ld);    \
-        vr0 = *(const uint4 *)(vg0 + (j) * 64);               \
-        vr1 = *(const uint4 *)(vg1 + (j) * 64);               \
+#define ATT_GLOAD(j)                                                        \
+    do {                                                                    \
+        const unsigned kj_ = (unsigned)(j) * kstep, vj_ = (unsigned)(j) * 128u; \
+        kr0 = *(const uint4 *)(kbase + (ko0 + kj_));                        \
+        kr1 = *(const uint4 *)(kbase + (ko1 + kj_));                        \
+        vr0 = *(const uint4 *)(vbase + (vo0 + vj_));                        \
+        vr1 = *(const uint4 *)(vbase + (vo1 + vj_));                        \
     } while (0)
 #define ATT_LSTORE(buf)                                                                            \
     do {                                                                                           \

@@ -411,9 +411,19 @@ int capture_positions(LaneJob &j, int n_prompt, int n_pos, hipGraph_t *g, hipGra
         if (crc == WM_OK) crc = wm_model_close_step(c, j.Bg, n_prompt, true, nullptr, 0, m->ts_on);
     }
     hipError_t ce = hipStreamEndCapture(c->stream, g);
-    if (crc != WM_OK) return crc;
-    WM_HIP(ce);
-    WM_HIP(hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
+    if (crc != WM_OK || ce != hipSuccess) {   // a half-captured graph is of no use: do not leave it behind
+        if (ce == hipSuccess && *g) (void)hipGraphDestroy(*g);
+        *g = nullptr;
+        if (crc != WM_OK) return crc;
+        WM_HIP(ce);
+    }
+    if (hipGraphInstantiate(ge, *g, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGraphDestroy(*g);
+        *g = nullptr;
+        *ge = nullptr;
+        wm_set_error("hipGraphInstantiate failed for the %d-position decode graph", n_pos);
+        return WM_ERR_HIP;
+    }
     return WM_OK;
 }
 
