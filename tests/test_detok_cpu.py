@@ -149,3 +149,42 @@ def test_language_table_matches_the_tokenizer_order_of_transformers():
     diff = [(i, a, b) for i, (a, b) in enumerate(zip(ours, theirs)) if a != b]
     assert diff == [(20, "iw", "he")], diff
     assert list(HF)[99] == "yue"                      # large-v3's 100th language id (50358)
+
+
+def test_detokenize_roundtrips_arbitrary_text_property(tmp_path):
+    """Property test (hypothesis): any text, cut into arbitrary byte-level pieces, decodes back to itself -- including
+    pieces that split a multi-byte character, and the parser takes both raw UTF-8 and \\uXXXX-escaped vocab files."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    import openai_whisper_coreml_amd as pkg
+    b2u = bytes_to_unicode()
+    counter = [0]
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.text(min_size=0, max_size=40), st.lists(st.integers(1, 6), min_size=1, max_size=40), st.booleans())
+    def check(text, cuts, ascii_json):
+        raw = text.encode("utf-8")
+        pieces, i = [], 0
+        for c in cuts:
+            if i >= len(raw):
+                break
+            pieces.append(raw[i:i + c])
+            i += c
+        if i < len(raw):
+            pieces.append(raw[i:])
+        vocab, ids = {}, []
+        for p in pieces:
+            key = "".join(b2u[b] for b in p)
+            vocab.setdefault(key, len(vocab))
+            ids.append(vocab[key])
+        counter[0] += 1
+        path = os.path.join(tmp_path, "v%d.json" % counter[0])
+        with open(path, "w", encoding="utf-8") as f:
+            json.dump(vocab, f, ensure_ascii=ascii_json)
+        v = pkg.binding.Vocab(path)
+        try:
+            assert v.decode(ids) == text
+        finally:
+            v.close()
+
+    check()

@@ -195,3 +195,43 @@ def test_c_abi_partition_and_gather_packing_match_the_python_path():
     assert lib.wm_multi_unpack_tokens(P(gathered), world, per, max_new, n_chunks, P(out_t), P(out_l)) == 0
     assert np.array_equal(out_t, toks) and np.array_equal(out_l, lens)
     assert lib.wm_multi_unpack_tokens(P(gathered), world, per, max_new, world * per + 1, P(out_t), P(out_l)) != 0
+
+
+def test_c_abi_pack_unpack_roundtrip_property():
+    """Property test (hypothesis): wm_multi_partition / wm_multi_pack_tokens / wm_multi_unpack_tokens -- the host-only pieces
+    of the one-process-all-GPUs split -- reproduce every chunk's (length, tokens) for any chunk count, world size and
+    max_new, and agree with sharding.partition (the torch.distributed host)."""
+    import ctypes
+    import pytest
+    pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    import openai_whisper_coreml_amd as pkg
+    lib = pkg.load_library()
+
+    @settings(max_examples=80, deadline=None)
+    @given(st.integers(0, 130), st.integers(1, 9), st.integers(0, 12), st.integers(0, 2 ** 31 - 1))
+    def check(n_chunks, world, max_new, seed):
+        rng = np.random.default_rng(seed)
+        toks = rng.integers(0, 51866, size=(n_chunks, max_new)).astype(np.int32)
+        lens = rng.integers(0, max_new + 1, size=n_chunks).astype(np.int32)
+        per = -(-n_chunks // world)
+        gathered = np.zeros((world, per, 1 + max_new), np.int32)
+        covered = []
+        for r in range(world):
+            lo, hi = ctypes.c_int(), ctypes.c_int()
+            assert lib.wm_multi_partition(n_chunks, world, r, ctypes.byref(lo), ctypes.byref(hi)) == 0
+            assert (lo.value, hi.value) == S.partition(n_chunks, world, r)
+            covered += list(range(lo.value, hi.value))
+            t = np.ascontiguousarray(toks[lo.value:hi.value])
+            l = np.ascontiguousarray(lens[lo.value:hi.value])
+            assert lib.wm_multi_pack_tokens(t.ctypes.data_as(ctypes.c_void_p), l.ctypes.data_as(ctypes.c_void_p),
+                                            hi.value - lo.value, per, max_new,
+                                            gathered[r].ctypes.data_as(ctypes.c_void_p)) == 0
+        assert covered == list(range(n_chunks))
+        out_t = np.full((n_chunks, max_new), -7, np.int32)
+        out_l = np.full(n_chunks, -7, np.int32)
+        assert lib.wm_multi_unpack_tokens(gathered.ctypes.data_as(ctypes.c_void_p), world, per, max_new, n_chunks,
+                                          out_t.ctypes.data_as(ctypes.c_void_p), out_l.ctypes.data_as(ctypes.c_void_p)) == 0
+        assert np.array_equal(out_t, toks) and np.array_equal(out_l, lens)
+
+    check()
