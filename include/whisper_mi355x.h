@@ -223,6 +223,20 @@ WM_API int wm_vocab_size(const wm_vocab *v);
 WM_API int wm_detokenize(const wm_vocab *v, const int32_t *ids, int n, int skip_special, char *buf, size_t cap,
                   size_t *needed);
 
+/* ------------------------------------------------ WAV reader + 30 s chunker (host only) --- */
+/* The step BEFORE the path: the reference records 16 kHz mono 16-bit LinearPCM to query.wav
+ * (AudioRecorder.swift:56-61), reads it back through AVFoundation (:74-86) and zero-pads / truncates to one 30 s window
+ * (ContentView.swift:57-60).  For a dlopen-only host: the same file format in, and the reference's pad rule applied per
+ * window, so a recording of any length becomes [n_chunks][480000] int16 (x = s / 32768 inside the front end) for
+ * wm_logmel / wm_transcribe_greedy / wm_multi_transcribe_greedy.  Anything but 16 kHz mono 16-bit PCM is WM_ERR_IO. */
+typedef struct wm_wav wm_wav;
+WM_API int wm_wav_open(const char *path, wm_wav **out);
+WM_API void wm_wav_close(wm_wav *w);
+WM_API long wm_wav_num_samples(const wm_wav *w);
+WM_API int wm_wav_num_chunks(const wm_wav *w);   /* ceil(samples / 480000), at least 1 */
+/* windows [first_chunk, first_chunk + n_chunks) -> out int16 [n_chunks][480000], the last window zero-padded */
+WM_API int wm_wav_read_chunks(const wm_wav *w, int first_chunk, int n_chunks, int16_t *out);
+
 /* ------------------------------------------------------------ device memory helpers --- */
 /* For callers that keep inputs resident in HBM (bench.py; a Swift host would use them to
  * avoid the 5.7 MB/chunk PCIe round trip of the reference ABI). */

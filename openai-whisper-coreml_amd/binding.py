@@ -122,6 +122,9 @@ def load_library(path=None):
         "wm_vocab_load": [ctypes.c_char_p, pp],
         "wm_vocab_size": [vp],
         "wm_detokenize": [vp, vp, ip, ip, vp, sz, vp],
+        "wm_wav_open": [ctypes.c_char_p, pp],
+        "wm_wav_num_chunks": [vp],
+        "wm_wav_read_chunks": [vp, ip, ip, vp],
         "wm_multi_create": [ctypes.POINTER(wm_dims), vp, ip, pp],
         "wm_multi_size": [vp],
         "wm_multi_device_ctx": [vp, ip, pp],
@@ -140,6 +143,10 @@ def load_library(path=None):
     lib.wm_multi_destroy.restype = None
     lib.wm_vocab_free.argtypes = [vp]
     lib.wm_vocab_free.restype = None
+    lib.wm_wav_close.argtypes = [vp]
+    lib.wm_wav_close.restype = None
+    lib.wm_wav_num_samples.argtypes = [vp]
+    lib.wm_wav_num_samples.restype = ctypes.c_long
     if path is None:
         _lib = lib
     return lib
@@ -408,6 +415,40 @@ class Vocab:
     def close(self):
         if getattr(self, "handle", None) is not None and self.handle:
             self.lib.wm_vocab_free(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Wav:
+    """wm_wav: 16 kHz mono 16-bit RIFF/WAVE reader + 30 s chunker behind the C ABI (host only)."""
+
+    def __init__(self, path):
+        self.lib = load_library()
+        self.handle = ctypes.c_void_p()
+        _check(self.lib, self.lib.wm_wav_open(str(path).encode(), ctypes.byref(self.handle)))
+
+    @property
+    def num_samples(self):
+        return int(self.lib.wm_wav_num_samples(self.handle))
+
+    @property
+    def num_chunks(self):
+        return int(self.lib.wm_wav_num_chunks(self.handle))
+
+    def chunks(self, first=0, n=None):
+        n = self.num_chunks - first if n is None else n
+        out = np.empty((n, N_SAMPLES), dtype=np.int16)
+        _check(self.lib, self.lib.wm_wav_read_chunks(self.handle, int(first), int(n), _ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle:
+            self.lib.wm_wav_close(self.handle)
             self.handle = ctypes.c_void_p()
 
     def __del__(self):

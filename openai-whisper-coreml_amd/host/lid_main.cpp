@@ -14,7 +14,7 @@
 //        SOT 50258 -> decoder -> arg-max over 50259...50357          -> wm_detect_language()
 //     print language, print elapsed seconds                           (Whisper.swift:39, ContentView.swift:63)
 //
-// usage: lid_main <libwhisper_mi355x.so> <model: tiny.en|base|small|large-v2> [weights.wm | synthetic:<seed>] [pcm_f32.raw]
+// usage: lid_main <libwhisper_mi355x.so> <model: tiny.en|base|small|large-v2> [weights.wm | synthetic:<seed>] [query.wav | pcm_f32.raw]
 #include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -63,10 +63,22 @@ int main(int argc, char **argv) {
     if (st == WM_OK) st = wm_finalize(ctx);
     if (st != WM_OK) { fprintf(stderr, "weights: %s\n", wm_last_error()); return 1; }
 
-    // the recording: raw little-endian f32 mono 16 kHz, or 10 s of a 440 Hz tone (the app records 10 s,
-    // ContentView.swift:47)
+    // the recording: query.wav as AudioRecorder.swift:56-61 writes it (16 kHz mono 16-bit, read through the library's
+    // wm_wav_* since there is no AVFoundation here; samples s -> s / 32768 as AVAudioFile's Float32 view gives them),
+    // raw little-endian f32 mono 16 kHz, or 10 s of a 440 Hz tone (the app records 10 s, ContentView.swift:47)
     std::vector<float> audio;
-    if (argc > 4) {
+    const std::string rec = argc > 4 ? argv[4] : "";
+    if (rec.size() > 4 && rec.compare(rec.size() - 4, 4, ".wav") == 0) {
+        LOAD(wm_wav_open) LOAD(wm_wav_close) LOAD(wm_wav_num_samples) LOAD(wm_wav_read_chunks)
+        wm_wav *wav = nullptr;
+        if (wm_wav_open(rec.c_str(), &wav) != WM_OK) { fprintf(stderr, "wm_wav_open: %s\n", wm_last_error()); return 1; }
+        std::vector<int16_t> first(480000);
+        if (wm_wav_read_chunks(wav, 0, 1, first.data()) != WM_OK) { fprintf(stderr, "wm_wav_read_chunks: %s\n", wm_last_error()); return 1; }
+        const long ns = wm_wav_num_samples(wav);
+        audio.resize(ns < 480000 ? (size_t)ns : (size_t)480000);
+        for (size_t i = 0; i < audio.size(); ++i) audio[i] = (float)first[i] / 32768.0f;
+        wm_wav_close(wav);
+    } else if (argc > 4) {
         FILE *f = fopen(argv[4], "rb");
         if (!f) { fprintf(stderr, "cannot open %s\n", argv[4]); return 1; }
         float buf[4096];

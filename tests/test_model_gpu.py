@@ -342,6 +342,22 @@ def test_cpp_host_harness_mirrors_the_swift_flow(pkg):
     assert r.returncode == 0, r.stderr
     lines = r.stdout.strip().splitlines()
     assert lines[0] in pkg.Whisper.LANGUAGES and float(lines[1]) > 0
+    # the same flow from query.wav (AudioRecorder.swift:56-61's format) through the library's own WAV reader: identical
+    # language to feeding the same samples through the Python mirror of the Swift surface
+    import importlib
+    import tempfile
+    A = importlib.import_module("openai_whisper_coreml_amd.audio")
+    x16 = np.round(tone_chunk(3)[:160000] * 32767).astype(np.int16)          # 10 s, as the app records
+    with tempfile.TemporaryDirectory() as td:
+        wav = os.path.join(td, "query.wav")
+        A.write_wav_int16(wav, x16)
+        r2 = subprocess.run([exe, pkg.binding.LIB_PATH, "base", "synthetic:3", wav], capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr
+    wh = pkg.Whisper("base", synthetic_seed=3)
+    audio = np.zeros(480000, np.float64)
+    audio[:160000] = (x16.astype(np.float32) / np.float32(32768.0)).astype(np.float64)
+    assert r2.stdout.strip().splitlines()[0] == wh.decode(wh.encode(audio))
+    wh.ctx.close()
 
 
 def test_base_geometry_batch32(pkg):

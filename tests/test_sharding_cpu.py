@@ -235,3 +235,50 @@ def test_c_abi_pack_unpack_roundtrip_property():
         assert np.array_equal(out_t, toks) and np.array_equal(out_l, lens)
 
     check()
+
+
+def test_c_abi_wav_reader_and_chunker(tmp_path):
+    """SURVEY 8f rank 1 behind the C ABI (wm_wav_*): the file AudioRecorder.swift:56-61 writes (16 kHz mono 16-bit PCM) in,
+    30 s windows out with ContentView.swift:57-60's zero-pad rule per window -- equal to the Python path (audio.py / the
+    standard `wave` module), including extra RIFF chunks before the data, odd-sized chunks, and the error cases."""
+    import struct
+    import wave
+    import pytest
+    import openai_whisper_coreml_amd as pkg
+    A = importlib.import_module("openai_whisper_coreml_amd.audio")
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 479999, 480000, 480001, 16000 * 75 + 3):
+        x = rng.integers(-32768, 32768, size=n).astype(np.int16)
+        p = os.path.join(tmp_path, "a%d.wav" % n)
+        A.write_wav_int16(p, x)
+        w = pkg.binding.Wav(p)
+        want = A.wav_to_chunks(p)
+        assert w.num_samples == n and w.num_chunks == want.shape[0]
+        assert np.array_equal(w.chunks(), want)
+        if w.num_chunks > 1:
+            assert np.array_equal(w.chunks(1, 1), want[1:2])
+        with pytest.raises(pkg.binding.WhisperError, match="outside"):
+            w.chunks(w.num_chunks, 1)
+        w.close()
+    # a LIST chunk of odd size before the data, and a WAVE_FORMAT_EXTENSIBLE header
+    x = rng.integers(-3000, 3000, size=1234).astype(np.int16)
+    fmt_ext = struct.pack("<HHIIHHHHIH14s", 0xFFFE, 1, 16000, 32000, 2, 16, 22, 16, 4, 1, b"\x00\x00\x00\x00\x10\x00\x80\x00\x00\xaa\x00\x38\x9b\x71")
+    body = b"WAVE" + b"LIST" + struct.pack("<I", 5) + b"hello" + b"\x00" + b"fmt " + struct.pack("<I", len(fmt_ext)) + fmt_ext \
+        + b"data" + struct.pack("<I", x.nbytes) + x.tobytes()
+    p = os.path.join(tmp_path, "ext.wav")
+    open(p, "wb").write(b"RIFF" + struct.pack("<I", len(body)) + body)
+    w = pkg.binding.Wav(p)
+    assert w.num_samples == 1234 and np.array_equal(w.chunks()[0, :1234], x) and not w.chunks()[0, 1234:].any()
+    w.close()
+    # errors: not RIFF, wrong rate, stereo, 8-bit, missing file
+    open(os.path.join(tmp_path, "junk.wav"), "wb").write(b"not a wave file at all")
+    with pytest.raises(pkg.binding.WhisperError, match="RIFF"):
+        pkg.binding.Wav(os.path.join(tmp_path, "junk.wav"))
+    for rate, ch, width, tag in ((44100, 1, 2, "rate"), (16000, 2, 2, "stereo"), (16000, 1, 1, "u8")):
+        p = os.path.join(tmp_path, tag + ".wav")
+        with wave.open(p, "wb") as f:
+            f.setnchannels(ch); f.setsampwidth(width); f.setframerate(rate); f.writeframes(b"\x00" * 64)
+        with pytest.raises(pkg.binding.WhisperError, match="16 kHz mono 16-bit"):
+            pkg.binding.Wav(p)
+    with pytest.raises(pkg.binding.WhisperError, match="cannot open"):
+        pkg.binding.Wav(os.path.join(tmp_path, "missing.wav"))
