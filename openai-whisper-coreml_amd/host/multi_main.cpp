@@ -3,7 +3,7 @@
 // SURVEY.md 8e.  No torch, no launcher: wm_multi_create(devices[], n) -> weights on every device -> one
 // wm_multi_transcribe_greedy over a recording cut into 30 s chunks (ContentView.swift:57-60's pad rule per window).
 //
-// usage: multi_main <libwhisper_mi355x.so> <model> <n_gpus> <n_chunks> [max_new]
+// usage: multi_main <libwhisper_mi355x.so> <model> <n_gpus> <n_chunks | recording.wav> [max_new]
 // prints: one line per chunk "chunk i: len tok tok ...", then "identical_to_single_gpu 1|0" (the same chunks through a
 // plain single-device wm_transcribe_greedy on device 0) and the wall time.
 #include <dlfcn.h>
@@ -37,7 +37,22 @@ int main(int argc, char **argv) {
     else if (model == "large-v2") d = {80, 1500, 1280, 20, 32, 51865, 448, 1280, 20, 32};
     else if (model == "large-v3") d = {128, 1500, 1280, 20, 32, 51866, 448, 1280, 20, 32};
     else { fprintf(stderr, "unknown model %s\n", argv[2]); return 2; }
-    const int n_gpus = atoi(argv[3]), n_chunks = atoi(argv[4]), max_new = argc > 5 ? atoi(argv[5]) : 8;
+    // argv[4]: a chunk count (synthetic recording) or a 16 kHz mono 16-bit .wav of any length (cut into 30 s windows by the
+    // library's own reader, wm_wav_*: the long-audio front door of SURVEY.md 8f rank 1 for a host without AVFoundation)
+    const std::string rec = argv[4];
+    const bool from_wav = rec.size() > 4 && rec.compare(rec.size() - 4, 4, ".wav") == 0;
+    std::vector<int16_t> pcm;
+    int n_chunks = from_wav ? 0 : atoi(argv[4]);
+    if (from_wav) {
+        LOAD(wm_wav_open) LOAD(wm_wav_close) LOAD(wm_wav_num_chunks) LOAD(wm_wav_read_chunks)
+        wm_wav *wav = nullptr;
+        if (wm_wav_open(rec.c_str(), &wav) != WM_OK) { fprintf(stderr, "wm_wav_open: %s\n", wm_last_error()); return 1; }
+        n_chunks = wm_wav_num_chunks(wav);
+        pcm.resize((size_t)n_chunks * 480000);
+        if (wm_wav_read_chunks(wav, 0, n_chunks, pcm.data()) != WM_OK) { fprintf(stderr, "wm_wav_read_chunks: %s\n", wm_last_error()); return 1; }
+        wm_wav_close(wav);
+    }
+    const int n_gpus = atoi(argv[3]), max_new = argc > 5 ? atoi(argv[5]) : 8;
     std::vector<int> devs(n_gpus);
     for (int i = 0; i < n_gpus; ++i) devs[i] = i;
     wm_multi *m = nullptr;
@@ -50,8 +65,8 @@ int main(int argc, char **argv) {
         }
     }
     // a "recording" of n_chunks windows: amplitude-modulated tones, int16 (AudioRecorder.swift:56-61 records LinearPCM)
-    std::vector<int16_t> pcm((size_t)n_chunks * 480000);
-    for (int c = 0; c < n_chunks; ++c)
+    if (!from_wav) pcm.resize((size_t)n_chunks * 480000);
+    for (int c = 0; c < (from_wav ? 0 : n_chunks); ++c)
         for (int i = 0; i < 480000; ++i) {
             const double t = i / 16000.0;
             pcm[(size_t)c * 480000 + i] = (int16_t)lrint(9000.0 * sin(2 * M_PI * (200 + 370 * (c % 7)) * t) * (0.5 + 0.5 * sin(2 * M_PI * 0.3 * t)));

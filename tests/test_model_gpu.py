@@ -960,6 +960,25 @@ def test_wm_multi_single_process_all_gpus_path(pkg):
     assert r.returncode == 0, r.stderr
     lines = [l for l in r.stdout.strip().splitlines() if l.startswith(("chunk ", "identical_"))]   # RCCL prints a banner
     assert len(lines) == 6 and lines[5] == "identical_to_single_gpu 1", r.stdout
+    # a recording of arbitrary length through the library's own WAV reader + chunker (wm_wav_*): 70 s -> 3 windows
+    import tempfile
+    A = importlib.import_module("openai_whisper_coreml_amd.audio")
+    x16 = np.round(np.concatenate([tone_chunk(1), tone_chunk(4), tone_chunk(2)[:160000]]) * 32767).astype(np.int16)
+    with tempfile.TemporaryDirectory() as td:
+        wav = os.path.join(td, "long.wav")
+        A.write_wav_int16(wav, x16)
+        r = subprocess.run([exe, pkg.binding.LIB_PATH, "tiny.en", "1", wav, "6"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        lines = [l for l in r.stdout.strip().splitlines() if l.startswith(("chunk ", "identical_"))]
+        assert len(lines) == 4 and lines[3] == "identical_to_single_gpu 1", r.stdout
+        # ... equal to the Python path on the same file (device-generated synthetic weights, seed 11, in both)
+        c = pkg.binding.Context(pkg.binding.MODEL_DIMS["tiny.en"])
+        c.init_synthetic(11)
+        c.finalize()
+        want, _ = c.transcribe_greedy(A.wav_to_chunks(wav), [50257, 50362, 10, 11], 6)
+        got = np.array([[int(t) for t in l.split()[3:]] for l in lines[:3]])
+        assert np.array_equal(got, want)
+        c.close()
 
 
 def test_converted_checkpoints_load_and_match_the_oracle(pkg, tmp_path):
