@@ -132,6 +132,39 @@ struct Whisper {
         return (0..<chunks).map { c in Array(tokens[c * Int(maxNew)..<c * Int(maxNew) + Int(lens[c])]) }
     }
 
+    /// The same from a recording on disk -- query.wav as AudioRecorder.swift:56-61 writes it (16 kHz mono 16-bit) -- through the
+    /// library's own reader / chunker (wm_wav_*: no AVFoundation on a Linux host), with an optional per-window token budget
+    /// (wm_set_token_budgets: a window that has used it up leaves the decode like one that has emitted `eot`).
+    func transcribe(wav path: String, prompt: [Int32] = [50258, 50259, 50359, 50363], maxNew: Int32 = 224,
+                    eot: Int32 = 50257, budgets: [Int32]? = nil) throws -> [[Int32]] {
+        typealias WavOpenFn = @convention(c) (UnsafePointer<CChar>, UnsafeMutablePointer<OpaquePointer?>) -> Int32
+        typealias WavCountFn = @convention(c) (OpaquePointer) -> Int32
+        typealias WavReadFn = @convention(c) (OpaquePointer, Int32, Int32, UnsafeMutablePointer<Int16>) -> Int32
+        typealias BudgetFn = @convention(c) (OpaquePointer, UnsafePointer<Int32>?, Int32) -> Int32
+        let open: WavOpenFn = try sym("wm_wav_open")
+        let count: WavCountFn = try sym("wm_wav_num_chunks")
+        let read: WavReadFn = try sym("wm_wav_read_chunks")
+        let close: DestroyFn = try sym("wm_wav_close")
+        var w: OpaquePointer?
+        try check(open(path, &w))
+        defer { close(w!) }
+        let chunks = Int(count(w!))
+        var pcm = [Int16](repeating: 0, count: chunks * 480_000)
+        try check(read(w!, 0, Int32(chunks), &pcm))
+        if let b = budgets {
+            let setBudgets: BudgetFn = try sym("wm_set_token_budgets")
+            try check(setBudgets(ctx, b, Int32(b.count)))          // must be one per window
+        }
+        var tokens = [Int32](repeating: 0, count: chunks * Int(maxNew))
+        var lens = [Int32](repeating: 0, count: chunks)
+        let f: GreedyFn = try sym("wm_transcribe_greedy")
+        try pcm.withUnsafeBytes { p in
+            try check(f(ctx, p.baseAddress!, 0 /* WM_I16 */, Int32(chunks), prompt, Int32(prompt.count), maxNew, eot,
+                        &tokens, &lens, 0))
+        }
+        return (0..<chunks).map { c in Array(tokens[c * Int(maxNew)..<c * Int(maxNew) + Int(lens[c])]) }
+    }
+
     /// ids -> text with the tokenizer's vocab.json (wm_vocab_load / wm_detokenize; no vocabulary ships with the library).
     func text(of ids: [Int32], vocabJSON: String) throws -> String {
         let load: VocabLoadFn = try sym("wm_vocab_load")

@@ -1249,6 +1249,14 @@ def test_early_stop_equals_truncation_and_cuts_the_work(lively, pkg):
         want_t, want_l = _truncate_like_the_host(full, eot, np.minimum(budgets, NEW))
         got_t, got_l = ctx.transcribe_greedy(base[idx], prompt, NEW, eot=eot, budgets=budgets)
         assert np.array_equal(got_l, want_l) and np.array_equal(got_t, want_t), n
+    # degenerate budgets / stops: every row done after its FIRST generated token (the group is over after one burst)
+    one_t, one_l = ctx.transcribe_greedy(base, prompt, NEW, eot=-1, budgets=[1] * 7)
+    assert np.all(one_l == 1) and np.array_equal(one_t[:, 0], full7[:, 0]) and np.all(one_t[:, 1:] == -1)
+    for r in range(7):                                       # eot == a row's very first token
+        e = int(full7[r, 0])
+        want_t, want_l = _truncate_like_the_host(full7, e)
+        got_t, got_l = ctx.transcribe_greedy(base, prompt, NEW, eot=e)
+        assert np.array_equal(got_l, want_l) and np.array_equal(got_t, want_t) and got_l[r] == 1, r
     # budgets are consumed by one call and must match its B
     again, _ = ctx.transcribe_greedy(base, prompt, NEW, eot=-1)
     assert np.array_equal(again, full7)
