@@ -84,10 +84,14 @@ WmStopDev wm_model_stop_dev(const WmModel *m) {
 }
 
 void wm_model_drop_graphs(WmModel *m) {
-    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-    if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
-    if (m->graph_exec_k) { (void)hipGraphExecDestroy(m->graph_exec_k); m->graph_exec_k = nullptr; }
-    if (m->graph_k) { (void)hipGraphDestroy(m->graph_k); m->graph_k = nullptr; }
+    for (WmModel::GraphSet &g : m->graph_sets) {
+        if (g.e1) (void)hipGraphExecDestroy(g.e1);
+        if (g.g1) (void)hipGraphDestroy(g.g1);
+        if (g.ek) (void)hipGraphExecDestroy(g.ek);
+        if (g.gk) (void)hipGraphDestroy(g.gk);
+    }
+    m->graph_sets.clear();
+    m->graph_cur = -1;
 }
 
 WmTsDev wm_model_ts_dev(const WmModel *m) {

@@ -145,15 +145,22 @@ struct WmModel {
     bool budget_on = false;
     int stop_eot = -1;
     std::vector<int32_t> budget_host;  // wm_set_token_budgets: per-chunk budgets of the NEXT call (empty: none)
-    // captured decode step (one hipGraph replayed for every position)
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    int graph_B = 0, graph_n_prompt = 0, graph_cap_b = 0, graph_mask = 0;
-    // ... and WM_BURST consecutive positions as ONE graph (the arg-max kernel advances the device-side position, so
-    // consecutive positions do not depend on the host): 1/8 of the graph launches, no launch-queue bubbles between them
-    hipGraph_t graph_k = nullptr;
-    hipGraphExec_t graph_exec_k = nullptr;
-    int graph_burst = 0, graph_stop_key = 0;
+    // Captured decode steps: one hipGraph of ONE position, and one of WM_BURST consecutive positions (the arg-max kernel
+    // advances the device-side position, so consecutive positions do not depend on the host: 1/8 of the graph launches).
+    // Everything a capture bakes into its kernel arguments is in the key; a lane keeps the last few shapes it ran
+    // (a server alternating between batch sizes, bench.py's groups of 56 / 48 chunks landing on different lanes from one
+    // pass to the next) instead of re-capturing ~2300 launches every time the shape changes (measured: the capture is
+    // host work of a few ms that hides behind the lane's own encoder, so this is tidiness, not throughput).
+    struct GraphSet {
+        int B = 0, n_prompt = 0, cap_b = 0, mask = 0, stop_key = 0, burst = 0;
+        hipGraph_t g1 = nullptr, gk = nullptr;
+        hipGraphExec_t e1 = nullptr, ek = nullptr;
+        unsigned long stamp = 0;   // last use (LRU eviction)
+    };
+    static constexpr int kMaxGraphSets = 4;
+    std::vector<GraphSet> graph_sets;
+    int graph_cur = -1;            // the set of the decode being enqueued
+    unsigned long graph_clock = 0;
     unsigned *dmask = nullptr;   // [2][vpad/32] suppressed-token bitmaps (wm_set_suppress); [1] = first generated token
     bool mask_on = false;
     std::vector<unsigned> mask_host;  // host copy of the every-position bitmap

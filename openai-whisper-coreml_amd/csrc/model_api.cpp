@@ -433,17 +433,42 @@ int lane_graph(LaneJob &j, int n_prompt, int n_steps) {
     const int mk = (m->mask_on ? 1 : 0) | (m->ts_on ? 2 : 0);
     const int sk = m->stop_on ? (1 | (m->budget_on ? 2 : 0) | ((m->stop_eot + 2) << 2)) : 0;
     const int K = burst_len();
-    const bool same = m->graph_B == j.Bg && m->graph_n_prompt == n_prompt && m->graph_cap_b == m->cap_b &&
-                      m->graph_mask == mk && m->graph_stop_key == sk;
-    if (!same) wm_model_drop_graphs(m);
-    if (!m->graph_exec) WM_TRY(capture_positions(j, n_prompt, 1, &m->graph, &m->graph_exec));
-    if (K > 1 && n_steps >= K && (!m->graph_exec_k || m->graph_burst != K)) {
-        if (m->graph_exec_k) { (void)hipGraphExecDestroy(m->graph_exec_k); m->graph_exec_k = nullptr; }
-        if (m->graph_k) { (void)hipGraphDestroy(m->graph_k); m->graph_k = nullptr; }
-        WM_TRY(capture_positions(j, n_prompt, K, &m->graph_k, &m->graph_exec_k));
-        m->graph_burst = K;
+    int cur = -1;
+    for (size_t i = 0; i < m->graph_sets.size(); ++i) {
+        const WmModel::GraphSet &g = m->graph_sets[i];
+        if (g.B == j.Bg && g.n_prompt == n_prompt && g.cap_b == m->cap_b && g.mask == mk && g.stop_key == sk) cur = (int)i;
     }
-    m->graph_B = j.Bg; m->graph_n_prompt = n_prompt; m->graph_cap_b = m->cap_b; m->graph_mask = mk; m->graph_stop_key = sk;
+    if (cur < 0) {
+        if ((int)m->graph_sets.size() >= WmModel::kMaxGraphSets) {   // evict the least recently used shape
+            size_t old = 0;
+            for (size_t i = 1; i < m->graph_sets.size(); ++i)
+                if (m->graph_sets[i].stamp < m->graph_sets[old].stamp) old = i;
+            WmModel::GraphSet &g = m->graph_sets[old];
+            if (g.e1) (void)hipGraphExecDestroy(g.e1);
+            if (g.g1) (void)hipGraphDestroy(g.g1);
+            if (g.ek) (void)hipGraphExecDestroy(g.ek);
+            if (g.gk) (void)hipGraphDestroy(g.gk);
+            m->graph_sets.erase(m->graph_sets.begin() + (long)old);
+        }
+        WmModel::GraphSet g;
+        g.B = j.Bg; g.n_prompt = n_prompt; g.cap_b = m->cap_b; g.mask = mk; g.stop_key = sk;
+        m->graph_sets.push_back(g);
+        cur = (int)m->graph_sets.size() - 1;
+    }
+    m->graph_cur = cur;
+    WmModel::GraphSet &g = m->graph_sets[cur];
+    g.stamp = ++m->graph_clock;
+    if (!g.e1) {
+        const int rc = capture_positions(j, n_prompt, 1, &g.g1, &g.e1);
+        if (rc != WM_OK) { g.g1 = nullptr; g.e1 = nullptr; return rc; }
+    }
+    if (K > 1 && n_steps >= K && (!g.ek || g.burst != K)) {
+        if (g.ek) { (void)hipGraphExecDestroy(g.ek); g.ek = nullptr; }
+        if (g.gk) { (void)hipGraphDestroy(g.gk); g.gk = nullptr; }
+        const int rc = capture_positions(j, n_prompt, K, &g.gk, &g.ek);
+        if (rc != WM_OK) { g.gk = nullptr; g.ek = nullptr; return rc; }
+        g.burst = K;
+    }
     return WM_OK;
 }
 
@@ -453,12 +478,13 @@ int lane_burst(LaneJob &j, int n_prompt, int n_steps, bool use_graph, bool stop_
     WmModel *m = c->model;
     const int K = burst_len();
     const int k = n_steps - j.t < K ? n_steps - j.t : K;
-    if (use_graph && k == K && K > 1 && m->graph_exec_k) {
-        WM_HIP(hipGraphLaunch(m->graph_exec_k, c->stream));
+    const WmModel::GraphSet *g = use_graph ? &m->graph_sets[m->graph_cur] : nullptr;
+    if (use_graph && k == K && K > 1 && g->ek && g->burst == K) {
+        WM_HIP(hipGraphLaunch(g->ek, c->stream));
     } else {
         for (int i = 0; i < k; ++i) {
             if (use_graph) {
-                WM_HIP(hipGraphLaunch(m->graph_exec, c->stream));
+                WM_HIP(hipGraphLaunch(g->e1, c->stream));
             } else {
                 WM_TRY(wm_model_decode_step(c, j.Bg, false, 0, m->dims.n_vocab - 1, m->mask_on ? n_prompt - 1 : -1, m->ts_on));
                 WM_TRY(wm_model_close_step(c, j.Bg, n_prompt, true, nullptr, 0, m->ts_on));

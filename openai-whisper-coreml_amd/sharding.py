@@ -74,30 +74,38 @@ def run_grouped(plan, inflight, run_group, rows_per_step, max_new, dist=None, wo
     and exchange the token streams ONCE, after the last group, with a fixed-stride all-gather.
 
     run_group(worker, group_index, k) -> (tokens int32 [k * rows_per_step][max_new], lens int32 [k * rows_per_step]).
-    Which worker takes which group is a race (a queue of group indices); nothing observable depends on it: the
-    results are stored by group index and concatenated in plan order before the collective.
+    Worker w starts with group w (so that a repeated run -- warm-up, then the timed pass -- puts the same group sizes on
+    the same lanes and finds their captured decode graphs); after that, which worker takes which group is a race (a
+    queue of group indices).  Nothing observable depends on it: the results are stored by group index and concatenated
+    in plan order before the collective.
     Returns (per_group results in plan order, gathered (tokens, lens) or None when dist is None)."""
     import queue
     import threading
+    n_workers = max(1, int(inflight))
     todo = queue.Queue()
-    for g in range(len(plan)):
+    for g in range(n_workers, len(plan)):
         todo.put(g)
     results = [None] * len(plan)
     errors = []
 
     def worker(w):
+        first = True
         while True:
-            try:
-                g = todo.get_nowait()
-            except queue.Empty:
-                return
+            if first and w < len(plan):
+                g = w                      # deterministic first assignment
+            else:
+                try:
+                    g = todo.get_nowait()
+                except queue.Empty:
+                    return
+            first = False
             try:
                 results[g] = run_group(w, g, plan[g])
             except BaseException as e:   # surfaced on the caller's thread: a dead worker must not hang the job
                 errors.append(e)
                 return
 
-    th = [threading.Thread(target=worker, args=(w,)) for w in range(max(1, int(inflight)))]
+    th = [threading.Thread(target=worker, args=(w,)) for w in range(n_workers)]
     for t in th:
         t.start()
     for t in th:
