@@ -1,23 +1,21 @@
 // dec_kernels.hip -- the autoregressive decode step for gfx950 (SURVEY.md section 2 rows
-// K10-K14): batch-of-B single-token decoder pass with a KV cache.
+// K10-K14): one decoder position for a decode GROUP of 1 .. 128 sequences with KV caches.
 //
-// Regime: B <= 16 sequences, so every matrix product is a "skinny" GEMM that streams each
-// weight exactly once -- HBM-bound, and at Whisper's sizes latency-bound per launch.  Design:
-//   * dec_gemv: one workgroup per 16 output features; its NW waves split K; every lane
-//     issues all of its 16-byte weight loads (10 per lane = 10 KiB per wave in flight)
-//     BEFORE touching the activations, straight into VGPRs (no LDS round trip for data that
-//     is used once, non-temporal so the stream does not evict the KV cache from L2/MALL).
-//     The product runs on the matrix pipe: v_mfma_f32_16x16x32_bf16 with the batch padded
-//     to 16 rows -- the weight fragment a lane loaded (8 consecutive k of one output row)
-//     IS the B operand, no shuffle.  LayerNorm (two-pass fp32 statistics, rows split over the
-//     waves along K, normalised tile kept in wave-private LDS), bias, GELU, residual add,
-//     KV-cache append and the logits arg-max are fused in, so a decoder layer is 8 launches.
-//   * dec_attention: single-query attention over the bf16 K/V cache; 16 waves per (sequence,
-//     head), 8 lanes per 128-byte row, 4 loads per lane in flight; fp32 softmax; writes the
-//     bf16 head output the out-projection consumes.  Optional flash-decoding split over the
-//     keys (small batches) with a combine kernel.
-//   * the decode position lives in HBM (*pos_ptr) and is advanced by the arg-max kernel, so
-//     ONE captured hipGraph of the whole step replays for every position.
+// Regime: every matrix product is a skinny GEMM that streams each weight exactly once per group and position --
+// HBM-bound, and at Whisper's sizes latency-bound per launch.  Design (details at each kernel):
+//   * dec_gemv_kernel: a workgroup owns TN adjacent 16-row weight tiles and NBLK blocks of 16 batch rows (the batch is
+//     the M of v_mfma_f32_16x16x32_bf16); its waves split K by a rule that depends on K ONLY (bit-level batch
+//     invariance); weights are stored fragment-tiled (one coalesced dwordx4 per lane per k-step, straight into VGPRs),
+//     activations likewise; everything is requested up front (one memory round trip); LayerNorm is FOLDED into the
+//     weights (W' = W gamma) with the row statistics arriving as deterministic partial sums from the producer of the
+//     residual; bias, GELU, residual add (+ bf16 copy + next statistics), KV-cache append and the logits arg-max with the
+//     suppress bitmaps / timestamp rules are fused epilogues, so a decoder layer is 8 launches.
+//   * dec_rows_attn_kernel: single-query attention over a bf16 K/V cache as NS canonical row streams per (sequence,
+//     head) pair (8 cross, 4 self), 8 lanes per 128-byte row, fp32 online softmax per stream, one ordered merge -- the
+//     same arithmetic whatever the launch shape.  With early stop on it walks the compact list of LIVE rows.
+//   * argmax_embed_kernel: closes a position (arg-max reduce, timestamp decision, early-stop flags + live list, next
+//     token, next embedding + statistics) and advances the decode position, which lives in HBM (*pos_ptr) -- so ONE
+//     captured hipGraph of the whole position (and one of WM_BURST positions) replays for every position.
 #include <stdlib.h>
 
 #include <atomic>
