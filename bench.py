@@ -217,6 +217,10 @@ def main():
     ap.add_argument("--fuse", type=int, default=16,
                     help="consecutive steps (batches) decoded together as ONE group of fuse*batch chunks (<= 128): the "
                          "decoder weights are streamed once per group and position")
+    ap.add_argument("--weight-gain", type=float, default=4.0,
+                    help="matrix gain of the random-init weights (wm_init_synthetic_gain): 4 = the `lively` model whose tokens "
+                         "depend on the audio and on the decode history, so that the token cross-checks below can fail; "
+                         "1 = plain N(0, 0.02^2) (a nearly input-independent model).  Timing does not depend on it.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-early-stop", action="store_true", help="skip the additional early-stop workload")
     ap.add_argument("--no-single-batch", action="store_true",
@@ -247,8 +251,6 @@ def main():
         else:
             dist.init_process_group(backend=dist_backend)
 
-    # this harness supplies the concurrency itself (S host threads x one decode group each): one lane per call
-    os.environ.setdefault("WM_LANES", "1")
     import importlib
     import openai_whisper_coreml_amd as pkg
     B = pkg.binding
@@ -256,16 +258,22 @@ def main():
     dims = B.MODEL_DIMS[args.model]
     # WM_BENCH_LOCAL_DEVICE: device ordinal override (two ranks sharing one GPU in the one-GPU-box test)
     ctx = B.Context(dims, device=int(os.environ.get("WM_BENCH_LOCAL_DEVICE", local_rank)))
-    ctx.init_synthetic(20240928)
+    ctx.init_synthetic(20240928, matrix_gain=args.weight_gain)
     ctx.finalize()
 
     nb = args.batch
     F = max(1, min(args.fuse, 128 // nb if nb <= 128 else 1))
     S = max(1, args.inflight)
     F = min(F, max(1, -(-args.steps // S)))   # few timed steps: smaller groups rather than idle lanes
-    chunks = [structured_pcm16() if i == 0 else synth_pcm16(rank * nb * F + i) for i in range(nb * F)]
-    pcm = np.stack(chunks)
+    # EVERY chunk of the run is a different recording (seeded noise; chunk 0 of rank 0 the structured KAT-3 chunk): decode
+    # group g reads its own slice of the resident PCM, so a crossed row, cache or lane shows up in the token checks below
+    n_res = nb * max(F, args.steps, args.warmup if args.warmup > 0 else 0)
+    pcm = np.stack([structured_pcm16() if (i == 0 and rank == 0) else synth_pcm16(rank * n_res + i) for i in range(n_res)])
     d_pcm = ctx.to_device(pcm)
+    chunk_bytes = 480000 * 2
+
+    def pcm_at(first_chunk):
+        return ctypes.c_void_p(d_pcm.value + first_chunk * chunk_bytes)
     sot, eot = 50258, 50257
     prompt = [sot, sot + 1, sot + 101, sot + 105] if dims["n_vocab"] >= 51865 else [50257, 50362]
     max_new = args.new_tokens
@@ -276,8 +284,11 @@ def main():
     # (steps, fuse, inflight), identical on every rank -- and the token streams are exchanged ONCE per run with a
     # fixed-stride all-gather (sharding.run_grouped), so the collective never depends on which lane finished first.
     ctxs = [ctx] + [ctx.clone() for _ in range(S - 1)]
+    for c in ctxs:
+        c.set_lanes(1)   # this harness supplies the concurrency itself (S host threads x one decode group each)
     gathered = None
-    seen = []   # (steps in the group, tokens) of every finished group: compared after the timed region
+    seen = {}   # pass tag -> {group index: tokens}: compared after the timed region
+    pass_tag = ["warmup"]
     es_tokens = [0]
 
     t_origin = [time.perf_counter()]
@@ -293,11 +304,12 @@ def main():
         stage_sum = np.zeros(3)
         lock = threading.Lock()
         plan = sharding.plan_groups(n_steps, F, S)
+        first = np.concatenate([[0], np.cumsum(plan)])[:-1] * nb   # first resident chunk of every group
 
         def run_group(w, g, k):
             c = ctxs[w]
             ta = time.perf_counter()
-            toks, lens = c.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE,
+            toks, lens = c.transcribe_greedy(pcm_at(int(first[g]) % n_res), prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE,
                                              pcm_dtype=B.WM_I16, B=nb * k,
                                              budgets=group_budgets(g, nb * k) if early_stop else None)
             if early_stop:
@@ -310,7 +322,7 @@ def main():
                     np.round(c.last_stage_ms(), 1)), file=sys.stderr)
             with lock:
                 stage_sum[:] += c.last_stage_ms()
-                seen.append((k, toks))
+                seen.setdefault(pass_tag[0], {})[g] = toks
             return toks, lens
 
         _, g = sharding.run_grouped(plan, S, run_group, nb, max_new, dist=dist if (use_dist and collective) else None,
@@ -334,6 +346,7 @@ def main():
     warm_steps_run = max(args.warmup, args.steps) if args.warmup > 0 else 0
     run_steps(warm_steps_run)
     sync_all()
+    pass_tag[0] = "timed"
     t0 = time.perf_counter()
     t_origin[0] = t0
     stage = run_steps(args.steps)
@@ -345,19 +358,21 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # every group decoded the same resident chunks: groups of equal size must have produced identical tokens
-    # (bit-level determinism across lanes, graph replays and concurrency), and a smaller group the prefix rows
-    ref_by_k = {}
-    tokens_consistent = True
-    for k, toks in seen:
-        if k not in ref_by_k:
-            ref_by_k[k] = toks
-        elif not np.array_equal(ref_by_k[k], toks):
-            tokens_consistent = False
-    kmax = max(ref_by_k) if ref_by_k else 0
-    for k, toks in ref_by_k.items():
-        if k != kmax and not np.array_equal(toks, ref_by_k[kmax][:toks.shape[0]]):
-            tokens_consistent = False
+    # Token cross-checks (rank-local; every one of them can fail: the groups decode DIFFERENT chunks and, with the default
+    # --weight-gain 4, the rows are pairwise distinct and history-dependent).  (a) here: the warm-up pass ran the same plan,
+    # so group g of the warm-up and of the timed pass must agree bit for bit (graph replays, three lanes racing in a
+    # different order); (b) and (c) below, after the timed region: the first batch decoded ALONE (a group of nb rows on one
+    # lane) and group 0 decoded alone with eager launches must reproduce the rows they had inside the timed run.
+    pass_tag[0] = "after"
+    timed_tokens = seen.get("timed", {})
+    token_checks = {}
+    if args.steps > 0 and warm_steps_run == args.steps and args.warmup > 0:
+        wu = seen.get("warmup", {})
+        token_checks["warmup_pass_equals_timed_pass"] = bool(
+            len(wu) == len(timed_tokens) and all(np.array_equal(wu[g], timed_tokens[g]) for g in timed_tokens))
+    all_rows = np.concatenate([timed_tokens[g] for g in sorted(timed_tokens)], axis=0) if timed_tokens else np.zeros((0, max_new), np.int32)
+    distinct_rows = len({r.tobytes() for r in all_rows})
+    per_row = [len(set(r.tolist())) for r in all_rows]
 
     # Early stop: the same plan, but every chunk stops after a synthetic budget of uniform(40..200)
     # tokens instead of the forced 224 -- finished rows leave the attention walk, finished groups are not decoded further.
@@ -389,9 +404,11 @@ def main():
         sync_all()
         t1 = time.perf_counter()
         for _ in range(2):
-            ctx.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE, pcm_dtype=B.WM_I16, B=nb)
+            one_t, _ = ctx.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE, pcm_dtype=B.WM_I16, B=nb)
         ctx.sync()
         single_ms = (time.perf_counter() - t1) / 2 * 1e3
+        if 0 in timed_tokens:   # (b) the first batch alone == its rows inside group 0 of the timed run
+            token_checks["first_batch_alone_equals_its_rows_in_group0"] = bool(np.array_equal(one_t, timed_tokens[0][:nb]))
 
     # Roofline of the dominant kernel, at the decode-group size the timed region actually ran: a second pass of ONE group
     # of that size (one lane, eager launches) with every launch bracketed by HIP events on the launch stream.
@@ -407,8 +424,10 @@ def main():
         n_prof = 1 if grp_chunks > 16 else min(args.steps, 3)
         t_p0 = time.perf_counter()
         for _ in range(n_prof):
-            ctx.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE, pcm_dtype=B.WM_I16, B=grp_chunks)
+            prof_t, _ = ctx.transcribe_greedy(d_pcm, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE, pcm_dtype=B.WM_I16, B=grp_chunks)
         ctx.sync()
+        if 0 in timed_tokens and timed_tokens[0].shape[0] == grp_chunks:   # (c) eager, one lane == graphs, S lanes
+            token_checks["group0_eager_single_lane_equals_timed_run"] = bool(np.array_equal(prof_t, timed_tokens[0]))
         prof_wall_ms = (time.perf_counter() - t_p0) * 1e3
         prof_steps = n_prof * grp_steps          # batches ("steps") the profiled pass covered: n_prof groups of grp_steps
         prof = ctx.profile()
@@ -543,7 +562,13 @@ def main():
             "decoder_tok_per_s": (S * nb * world * max_new) / max(stage_s[2], 1e-9),   # S pipelines decode concurrently
             "tok_per_s_end_to_end": (nb * world * max_new * args.steps) / dt,
             "inflight_batches_per_gpu": S * F,
-            "tokens_consistent_across_groups": tokens_consistent,
+            # every cross-check of token_checks holds (each one can fail: distinct chunks per group, distinct rows)
+            "tokens_consistent_across_groups": bool(token_checks) and all(token_checks.values()),
+            "token_checks": token_checks,
+            "distinct_token_rows": distinct_rows, "token_rows": int(all_rows.shape[0]),
+            "distinct_tokens_per_row": {"min": int(min(per_row)) if per_row else 0,
+                                        "mean": float(np.mean(per_row)) if per_row else 0.0},
+            "weight_gain": args.weight_gain,
             # the literal BASELINE.json configs[3] figure: ONE batch of %d chunks in flight, nothing else on the GPU
             "value_batch8": (30.0 * nb / (single_ms * 1e-3)) if single_ms else None,
             "single_batch_latency_ms": single_ms,

@@ -105,6 +105,12 @@ WM_API int wm_load_weights(wm_ctx *ctx, const char *path);
 /* Deterministic synthetic weights generated ON DEVICE (hash-based, approx N(0, std^2));
  * identical values to weights.synthetic_state_dict(dims, seed) on the host. */
 WM_API int wm_init_synthetic(wm_ctx *ctx, uint64_t seed);
+/* The same generator with every weight MATRIX (conv / linear / token embedding; not the positional tables, biases or
+ * LayerNorm parameters) multiplied by matrix_gain -- weights.synthetic_state_dict(dims, seed, matrix_gain).  Gain 4 makes a
+ * random-init model whose token streams depend on the audio and on the decode history (N(0, 0.02^2) weights give a nearly
+ * input-independent one): what the token-level parity tests and bench.py's cross-checks decode.  A power of two keeps the
+ * values bf16-exact. */
+WM_API int wm_init_synthetic_gain(wm_ctx *ctx, uint64_t seed, float matrix_gain);
 /* Freeze weights: fuse QKV, permute conv taps, precompute tables.  Required before any
  * model call. */
 WM_API int wm_finalize(wm_ctx *ctx);
@@ -159,6 +165,11 @@ WM_API int wm_detect_language_probs(wm_ctx *ctx, const float *xa, int B, int32_t
 WM_API int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int B,
                          const int32_t *prompt, int n_prompt, int max_new, int32_t eot,
                          int32_t *tokens_out, int32_t *lens_out, wm_mem mem);
+
+/* Decode groups a wm_transcribe_greedy call on this context keeps in flight (1 .. 8 lanes; 0 = the default, $WM_LANES
+ * or 3).  1: the whole call (up to 128 chunks) is ONE decode group on the context's own stream -- what a host that runs
+ * its own concurrency over wm_clone'd contexts wants (bench.py), and what a test of one large group needs. */
+WM_API int wm_set_lanes(wm_ctx *ctx, int n_lanes);
 
 /* Logit filters of openai-whisper's greedy decode() (whisper/decoding.py SuppressTokens and SuppressBlank; SURVEY.md 8f
  * rank 3), applied inside the fused logits / arg-max kernel of wm_transcribe_greedy:

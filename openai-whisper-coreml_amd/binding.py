@@ -102,6 +102,7 @@ def load_library(path=None):
         "wm_get_tensor": [vp, ctypes.c_char_p, vp, sz],
         "wm_load_weights": [vp, ctypes.c_char_p],
         "wm_init_synthetic": [vp, ctypes.c_uint64],
+        "wm_init_synthetic_gain": [vp, ctypes.c_uint64, ctypes.c_float],
         "wm_finalize": [vp],
         "wm_get_dims": [vp, ctypes.POINTER(wm_dims)],
         "wm_encode": [vp, vp, ip, vp, ip],
@@ -109,6 +110,7 @@ def load_library(path=None):
         "wm_detect_language": [vp, vp, ip, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp, ip],
         "wm_transcribe_greedy": [vp, vp, ip, ip, vp, ip, ip, ctypes.c_int32, vp, vp, ip],
         "wm_set_token_budgets": [vp, vp, ip],
+        "wm_set_lanes": [vp, ip],
         "wm_dev_malloc": [vp, sz, pp],
         "wm_dev_free": [vp, vp],
         "wm_dev_upload": [vp, vp, vp, sz],
@@ -304,8 +306,12 @@ class Context:
     def load_weights(self, path):
         _check(self.lib, self.lib.wm_load_weights(self.handle, path.encode()))
 
-    def init_synthetic(self, seed):
-        _check(self.lib, self.lib.wm_init_synthetic(self.handle, int(seed)))
+    def init_synthetic(self, seed, matrix_gain=1.0):
+        """wm_init_synthetic / wm_init_synthetic_gain (matrix_gain 4: the `lively` random-init model of the token tests)."""
+        if matrix_gain == 1.0:
+            _check(self.lib, self.lib.wm_init_synthetic(self.handle, int(seed)))
+        else:
+            _check(self.lib, self.lib.wm_init_synthetic_gain(self.handle, int(seed), float(matrix_gain)))
 
     def finalize(self):
         _check(self.lib, self.lib.wm_finalize(self.handle))
@@ -363,6 +369,10 @@ class Context:
         self.lib.wm_set_timestamp_rules.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int32,
                                                     ctypes.c_int32]
         _check(self.lib, self.lib.wm_set_timestamp_rules(self.handle, 1 if enable else 0, timestamp_begin, eot, max_initial))
+
+    def set_lanes(self, n):
+        """Decode groups one transcribe_greedy call keeps in flight (0: default = $WM_LANES or 3; 1: one group per call)."""
+        _check(self.lib, self.lib.wm_set_lanes(self.handle, int(n)))
 
     def set_token_budgets(self, budgets):
         """Per-chunk token budgets of the NEXT transcribe_greedy call (len == its B; consumed by it)."""

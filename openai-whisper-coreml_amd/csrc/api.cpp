@@ -303,6 +303,9 @@ extern "C" int wm_logmel(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int n
 // The reference's symbol (bridge.h:11 / lib.rs:110-122).  The Rust crate's entry is re-entrant (immutable lazily
 // initialised state, lib.rs:11-14), so concurrent callers must not queue behind one another here either: a small pool of
 // lazily created front-end contexts (own stream, tables and staging each), handed out under a mutex and used outside it.
+// At most kGsMaxContexts (8) callers run concurrently -- a ninth waits for a context to come back --; the contexts live
+// for the rest of the process (the symbol has no teardown counterpart in the reference's ABI either: bridge.h declares
+// one function), a few MB of HBM each; $WM_DEVICE is read once, when the first context is made.
 namespace {
 constexpr int kGsMaxContexts = 8;
 std::mutex g_gs_mutex;
@@ -326,9 +329,12 @@ wm_ctx *gs_acquire() {
             g_gs_cv.wait(lock);
         }
     }
-    const char *dev = getenv("WM_DEVICE");
+    static const int device = [] {
+        const char *dev = getenv("WM_DEVICE");
+        return dev ? atoi(dev) : 0;
+    }();
     wm_ctx *c = nullptr;
-    if (wm_create_frontend(dev ? atoi(dev) : 0, &c) != WM_OK) {
+    if (wm_create_frontend(device, &c) != WM_OK) {
         fprintf(stderr, "generate_spectrogram: no usable MI355X context (%s); there is no CPU fallback\n", wm_last_error());
         abort();  // the reference panics (=abort across FFI) on its internal failures too
     }

@@ -14,7 +14,9 @@
 #include "wm_internal.h"
 
 struct wm_wav {
-    std::vector<int16_t> samples;
+    std::vector<unsigned char> raw;  // the file image (kept as read: ONE copy of the recording, whatever its size)
+    size_t data_off = 0;             // first byte of the data chunk
+    size_t n_samples = 0;
 };
 
 namespace {
@@ -66,20 +68,21 @@ extern "C" int wm_wav_open(const char *path, wm_wav **out) try {
     WM_REQUIRE(have_fmt, WM_ERR_IO, "'%s': no fmt chunk before the data", path);
     WM_REQUIRE(data_off != 0, WM_ERR_IO, "'%s': no data chunk", path);
     wm_wav *w = new wm_wav();
-    w->samples.resize(data_len / 2);
-    for (size_t i = 0; i < w->samples.size(); ++i) w->samples[i] = (int16_t)rd16(buf.data() + data_off + 2 * i);  // little endian
+    w->raw.swap(buf);   // no second copy: samples are decoded (little endian -> host int16) window by window on read
+    w->data_off = data_off;
+    w->n_samples = data_len / 2;
     *out = w;
     return WM_OK;
 } WM_API_CATCH
 
 extern "C" void wm_wav_close(wm_wav *w) { delete w; }
 
-extern "C" long wm_wav_num_samples(const wm_wav *w) { return w ? (long)w->samples.size() : 0; }
+extern "C" long wm_wav_num_samples(const wm_wav *w) { return w ? (long)w->n_samples : 0; }
 
 // ceil(n / 480000), at least one window (an empty recording is one silent chunk -- sharding.chunk_pcm's rule)
 extern "C" int wm_wav_num_chunks(const wm_wav *w) {
     if (!w) return 0;
-    const size_t n = w->samples.size();
+    const size_t n = w->n_samples;
     return n == 0 ? 1 : (int)((n + WM_N_SAMPLES - 1) / WM_N_SAMPLES);
 }
 
@@ -87,12 +90,13 @@ extern "C" int wm_wav_read_chunks(const wm_wav *w, int first_chunk, int n_chunks
     WM_REQUIRE(w && out && first_chunk >= 0 && n_chunks >= 0 && first_chunk + (long)n_chunks <= wm_wav_num_chunks(w),
                WM_ERR_INVALID, "wav_read_chunks: windows [%d, %d) outside the recording's %d", first_chunk,
                first_chunk + n_chunks, wm_wav_num_chunks(w));
-    const size_t n = w->samples.size();
+    const size_t n = w->n_samples;
     for (int c = 0; c < n_chunks; ++c) {
         const size_t lo = (size_t)(first_chunk + c) * WM_N_SAMPLES;
         const size_t have = lo < n ? (n - lo < (size_t)WM_N_SAMPLES ? n - lo : (size_t)WM_N_SAMPLES) : 0;
         int16_t *dst = out + (size_t)c * WM_N_SAMPLES;
-        if (have) memcpy(dst, w->samples.data() + lo, have * sizeof(int16_t));
+        const unsigned char *src = w->raw.data() + w->data_off + 2 * lo;
+        for (size_t i = 0; i < have; ++i) dst[i] = (int16_t)rd16(src + 2 * i);   // little endian, whatever the host
         memset(dst + have, 0, ((size_t)WM_N_SAMPLES - have) * sizeof(int16_t));  // ContentView.swift:57-60: zero-pad
     }
     return WM_OK;

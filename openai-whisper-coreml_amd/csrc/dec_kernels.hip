@@ -923,7 +923,7 @@ __device__ __forceinline__ unsigned hash32(unsigned x) {
 }
 __global__ __launch_bounds__(256) void synth_fill_kernel(void *dst, int is_bf16, size_t n, unsigned key,
                                                          float scale, int layout, int conv_c, int kpad,
-                                                         int kind) {
+                                                         int kind, float gain) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float v;
         if (kind == 2) {
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(void *dst, int is_bf16,
             const unsigned h1 = hash32((unsigned)i ^ key);
             const unsigned h2 = hash32(h1 + 0x85ebca6bu);
             const int s = (int)(h1 & 0xffffu) + (int)(h1 >> 16) + (int)(h2 & 0xffffu) + (int)(h2 >> 16);
-            v = __fmul_rn((float)(s - 131070), scale);
+            v = __fmul_rn(__fmul_rn((float)(s - 131070), scale), gain);  // two roundings, as on the host
         }
         size_t o = i;
         if (layout == WL_CONV) {
@@ -1028,9 +1028,11 @@ static void pick_shape(int epi, bool ln, int spw, int nw, int B, int n_tiles, in
     const int blocks = (B + 15) / 16;
     *tn = 1;
     *nblk = 1;
-    // one block, or a 16-wave K split (K = 4d at d >= 768: the multi-unit kernels are built for <= 8 waves -- launch
-    // bounds 512, register budget): one unit per workgroup, more workgroups along the batch
-    if (blocks < 2 || nw > 8) return;
+    // one block, a 16-wave K split (K = 4d at d >= 768: the multi-unit kernels are built for <= 8 waves -- launch bounds
+    // 512, register budget) or more than 8 k-steps per wave (K = 4d at d = 576 / 640: spw 12 / 10 on <= 8 waves -- the
+    // two-block kernel holds 2 x SPW activation fragments and exists for SPW <= 8 only): one unit per workgroup, more
+    // workgroups along the batch
+    if (blocks < 2 || nw > 8 || spw > 8) return;
     *nblk = env_nb == 1 ? 1 : 2;
     const bool wide = ln && (epi == DE_QKV || epi == DE_GELU || epi == DE_LOGITS) && *nblk == 2 && spw <= 6;
     if (!wide) return;
@@ -1318,7 +1320,7 @@ int wm_range_softmax(wm_ctx *ctx, const float *logits, long ldo, int B, int firs
     return WM_OK;
 }
 
-int wm_fill_synthetic(wm_ctx *ctx, const WmTensor &t, uint32_t seed, int tensor_id) {
+int wm_fill_synthetic(wm_ctx *ctx, const WmTensor &t, uint32_t seed, int tensor_id, float gain) {
     if (t.kind == 4) return WM_OK;  // sinusoids are computed on the host (model.cpp)
     const unsigned key = [&] {
         unsigned x = seed + (unsigned)tensor_id * 0x9E3779B9u;
@@ -1329,7 +1331,7 @@ int wm_fill_synthetic(wm_ctx *ctx, const WmTensor &t, uint32_t seed, int tensor_
     const float scale = (float)(std / 37837.22659);
     const int grid = (int)((t.n_elems + 255) / 256 < 16384 ? (t.n_elems + 255) / 256 : 16384);
     synth_fill_kernel<<<grid, 256, 0, ctx->stream>>>(t.ptr, t.is_bf16 ? 1 : 0, t.n_elems, key, scale, t.layout,
-                                                     t.conv_c, t.conv_kpad, t.kind);
+                                                     t.conv_c, t.conv_kpad, t.kind, gain);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

@@ -383,7 +383,7 @@ int wm_model_get_tensor(wm_ctx *ctx, const char *name, float *data, size_t n) {
     return WM_OK;
 }
 
-int wm_model_init_synthetic(wm_ctx *ctx, uint64_t seed) {
+int wm_model_init_synthetic(wm_ctx *ctx, uint64_t seed, float matrix_gain) {
     WmModel *m = ctx->model;
     WM_REQUIRE(m, WM_ERR_STATE, "context has no model");
     WM_REQUIRE(!m->shares_weights, WM_ERR_STATE, "a cloned context shares its parent's weights");
@@ -402,7 +402,10 @@ int wm_model_init_synthetic(wm_ctx *ctx, uint64_t seed) {
                 }
             WM_HIP(hipMemcpy(t.ptr, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
         } else {
-            WM_TRY(wm_fill_synthetic(ctx, t, (uint32_t)(seed & 0xffffffffu), (int)i));
+            // matrix_gain scales the MATRICES only (weights.synthetic_state_dict(..., matrix_gain)): not the learned
+            // positional table, biases or LayerNorm parameters -- the "lively" recipe of the token-level tests / bench.py
+            const bool scaled = t.kind == 0 && t.name.find("positional") == std::string::npos;
+            WM_TRY(wm_fill_synthetic(ctx, t, (uint32_t)(seed & 0xffffffffu), (int)i, scaled ? matrix_gain : 1.0f));
         }
         t.set = true;
     }

@@ -183,7 +183,7 @@ int wm_model_clone(wm_ctx *child, const wm_ctx *parent);
 int wm_model_reserve(wm_ctx *ctx, int B);
 int wm_model_set_tensor(wm_ctx *ctx, const char *name, const float *data, size_t n);
 int wm_model_get_tensor(wm_ctx *ctx, const char *name, float *data, size_t n);
-int wm_model_init_synthetic(wm_ctx *ctx, uint64_t seed);
+int wm_model_init_synthetic(wm_ctx *ctx, uint64_t seed, float matrix_gain);
 int wm_model_finalize(wm_ctx *ctx);
 // device-pointer cores
 int wm_model_encode_dev(wm_ctx *ctx, const float *d_mel, int B, float *d_xa_out /*nullable*/);
@@ -317,4 +317,4 @@ int wm_stop_init(wm_ctx *ctx, const WmStopDev &stop, int B);
 // initial timestamp-rule state of B sequences (before the first sampled token)
 int wm_ts_init(wm_ctx *ctx, const WmTsDev &ts, int B);
 int wm_range_softmax(wm_ctx *ctx, const float *logits, long ldo, int B, int first, int n, float *probs);
-int wm_fill_synthetic(wm_ctx *ctx, const WmTensor &t, uint32_t seed, int tensor_id);
+int wm_fill_synthetic(wm_ctx *ctx, const WmTensor &t, uint32_t seed, int tensor_id, float gain);

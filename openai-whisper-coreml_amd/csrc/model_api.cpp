@@ -44,7 +44,13 @@ extern "C" int wm_get_tensor(wm_ctx *ctx, const char *name, float *data, size_t 
 extern "C" int wm_init_synthetic(wm_ctx *ctx, uint64_t seed) try {
     WM_MODEL(ctx);
     (void)m;
-    return wm_model_init_synthetic(ctx, seed);
+    return wm_model_init_synthetic(ctx, seed, 1.0f);
+} WM_API_CATCH
+extern "C" int wm_init_synthetic_gain(wm_ctx *ctx, uint64_t seed, float matrix_gain) try {
+    WM_MODEL(ctx);
+    (void)m;
+    WM_REQUIRE(matrix_gain > 0.f && matrix_gain <= 64.f, WM_ERR_INVALID, "init_synthetic_gain: gain must be in (0, 64]");
+    return wm_model_init_synthetic(ctx, seed, matrix_gain);
 } WM_API_CATCH
 extern "C" int wm_finalize(wm_ctx *ctx) try {
     WM_MODEL(ctx);
@@ -65,6 +71,12 @@ extern "C" int wm_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t timestamp
     WM_TRY(wm_model_set_timestamp_rules(ctx, enable, timestamp_begin, eot, max_initial_timestamp_index));
     for (wm_ctx *lane : ctx->lanes)
         WM_TRY(wm_model_set_timestamp_rules(lane, enable, timestamp_begin, eot, max_initial_timestamp_index));
+    return WM_OK;
+} WM_API_CATCH
+extern "C" int wm_set_lanes(wm_ctx *ctx, int n_lanes) try {
+    WM_REQUIRE(ctx, WM_ERR_INVALID, "null context");
+    WM_REQUIRE(n_lanes >= 0 && n_lanes <= 8, WM_ERR_INVALID, "set_lanes: 0 (default) .. 8");
+    ctx->max_lanes = n_lanes;
     return WM_OK;
 } WM_API_CATCH
 extern "C" int wm_get_dims(const wm_ctx *ctx, wm_dims *out) try {
@@ -506,6 +518,10 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
                                     const int32_t *prompt, int n_prompt, int max_new, int32_t eot,
                                     int32_t *tokens_out, int32_t *lens_out, wm_mem mem) try {
     WM_MODEL(ctx);
+    // per-chunk token budgets set for THIS call (wm_set_token_budgets) are consumed by it whatever happens next: a call
+    // that fails validation must not leave them armed for a later, unrelated call with the same B
+    std::vector<int32_t> budgets;
+    budgets.swap(m->budget_host);
     WM_REQUIRE(m->finalized, WM_ERR_STATE, "model weights not finalised (wm_finalize)");
     WM_REQUIRE(pcm && prompt && tokens_out && lens_out, WM_ERR_INVALID, "null pointer");
     WM_REQUIRE(pcm_dtype == WM_I16 || pcm_dtype == WM_F32 || pcm_dtype == WM_F64, WM_ERR_INVALID, "bad pcm dtype");
@@ -516,9 +532,6 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
     for (int i = 0; i < n_prompt; ++i)
         WM_REQUIRE(prompt[i] >= 0 && prompt[i] < D.n_vocab, WM_ERR_INVALID, "prompt token %d out of range", prompt[i]);
     WM_REQUIRE(eot < D.n_vocab, WM_ERR_INVALID, "eot %d outside the vocabulary", eot);
-    // per-chunk token budgets set for THIS call (wm_set_token_budgets): consumed here
-    std::vector<int32_t> budgets;
-    budgets.swap(m->budget_host);
     WM_REQUIRE(budgets.empty() || (int)budgets.size() == B, WM_ERR_INVALID,
                "token budgets were set for %d chunks, the call has %d", (int)budgets.size(), B);
     for (auto &b : budgets) b = b > max_new ? max_new : b;
@@ -531,7 +544,7 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
     stop.budgets = budgets.empty() ? nullptr : budgets.data();
     // Split the B chunks into G balanced decode groups (<= WM_DEC_MAXB each, kGroupChunks preferred) and run
     // them on L lanes.  Per-kernel profiling keeps everything on the caller's context (one lane).
-    const int L = ctx->prof.on ? 1 : lane_limit();
+    const int L = ctx->prof.on ? 1 : (ctx->max_lanes > 0 ? ctx->max_lanes : lane_limit());
     int G;
     if (B <= kGroupChunks * L) {
         G = (B + kGroupChunks - 1) / kGroupChunks;

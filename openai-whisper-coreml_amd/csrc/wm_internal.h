@@ -135,6 +135,7 @@ struct wm_ctx {
     WmModel *model = nullptr;
     float stage_ms[3] = {0, 0, 0};
     std::vector<wm_ctx *> lanes;  // weight-sharing clones owned by this context (wm_transcribe_greedy)
+    int max_lanes = 0;            // wm_set_lanes: decode groups in flight per wm_transcribe_greedy call (0: $WM_LANES, default 3)
 };
 
 int wm_ctx_make_current(const wm_ctx *ctx);

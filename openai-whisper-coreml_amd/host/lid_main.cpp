@@ -73,7 +73,11 @@ int main(int argc, char **argv) {
         wm_wav *wav = nullptr;
         if (wm_wav_open(rec.c_str(), &wav) != WM_OK) { fprintf(stderr, "wm_wav_open: %s\n", wm_last_error()); return 1; }
         std::vector<int16_t> first(480000);
-        if (wm_wav_read_chunks(wav, 0, 1, first.data()) != WM_OK) { fprintf(stderr, "wm_wav_read_chunks: %s\n", wm_last_error()); return 1; }
+        if (wm_wav_read_chunks(wav, 0, 1, first.data()) != WM_OK) {
+            fprintf(stderr, "wm_wav_read_chunks: %s\n", wm_last_error());
+            wm_wav_close(wav);
+            return 1;
+        }
         const long ns = wm_wav_num_samples(wav);
         audio.resize(ns < 480000 ? (size_t)ns : (size_t)480000);
         for (size_t i = 0; i < audio.size(); ++i) audio[i] = (float)first[i] / 32768.0f;

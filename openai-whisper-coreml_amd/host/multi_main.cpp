@@ -49,7 +49,11 @@ int main(int argc, char **argv) {
         if (wm_wav_open(rec.c_str(), &wav) != WM_OK) { fprintf(stderr, "wm_wav_open: %s\n", wm_last_error()); return 1; }
         n_chunks = wm_wav_num_chunks(wav);
         pcm.resize((size_t)n_chunks * 480000);
-        if (wm_wav_read_chunks(wav, 0, n_chunks, pcm.data()) != WM_OK) { fprintf(stderr, "wm_wav_read_chunks: %s\n", wm_last_error()); return 1; }
+        if (wm_wav_read_chunks(wav, 0, n_chunks, pcm.data()) != WM_OK) {
+            fprintf(stderr, "wm_wav_read_chunks: %s\n", wm_last_error());
+            wm_wav_close(wav);
+            return 1;
+        }
         wm_wav_close(wav);
     }
     const int n_gpus = atoi(argv[3]), max_new = argc > 5 ? atoi(argv[5]) : 8;

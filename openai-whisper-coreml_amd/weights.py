@@ -117,8 +117,9 @@ def bf16_round_f32(v):
     return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
 
 
-def synthetic_state_dict(dims, seed=0):
-    """Deterministic synthetic weights (same values as wm_init_synthetic(ctx, seed))."""
+def synthetic_state_dict(dims, seed=0, matrix_gain=1.0):
+    """Deterministic synthetic weights (same values as wm_init_synthetic(ctx, seed); with matrix_gain != 1 as
+    wm_init_synthetic_gain: every matrix except the positional tables is multiplied by the gain before the bf16 rounding)."""
     sd = {}
     for tid, (name, shape, kind) in enumerate(tensor_specs(dims)):
         n = int(np.prod(shape))
@@ -130,7 +131,10 @@ def synthetic_state_dict(dims, seed=0):
             sd[name] = sinusoids(shape[0], shape[1])
         else:
             # matrices live in HBM as bf16 -> generate bf16-representable values; biases are f32
-            sd[name] = synthetic_values(seed, tid, n, STD[kind], bf16_round=(kind == K_MATRIX)).reshape(shape)
+            v = synthetic_values(seed, tid, n, STD[kind], bf16_round=False)
+            if kind == K_MATRIX and "positional" not in name:
+                v = v * np.float32(matrix_gain)
+            sd[name] = (bf16_round_f32(v) if kind == K_MATRIX else v).reshape(shape)
     return sd
 
 

@@ -35,6 +35,10 @@ def test_bench_distributed_branch_runs_at_world_size_one():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and line["steps"] == 6 and line["value"] > 0
     assert line["tokens_consistent_across_groups"] is True
+    # the three cross-checks ran, on pairwise distinct rows (6 batches of 8 different chunks, lively weights)
+    assert set(line["token_checks"]) == {"warmup_pass_equals_timed_pass", "first_batch_alone_equals_its_rows_in_group0",
+                                         "group0_eager_single_lane_equals_timed_run"}, line["token_checks"]
+    assert line["token_rows"] == 48 and line["distinct_token_rows"] >= 40, (line["token_rows"], line["distinct_token_rows"])
     assert line["config"]["decode_groups"] == [2, 2, 2]
     # the per-family table is self-consistent (VERDICT r2 "weak" #5): the families of the single-lane pass cannot add up
     # to more than that pass's own wall time

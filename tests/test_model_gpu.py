@@ -84,11 +84,14 @@ def tones(n, start=0):
     return np.stack([tone_chunk(start + i) for i in range(n)])
 
 
-def test_device_synthetic_generator_is_bit_identical(pkg):
+@pytest.mark.parametrize("gain", [1.0, 4.0, 3.0])
+def test_device_synthetic_generator_is_bit_identical(pkg, gain):
+    """wm_init_synthetic / wm_init_synthetic_gain == weights.synthetic_state_dict on the host, bit for bit (gain 3 is not a
+    power of two: the second rounding is part of the definition)."""
     dims = dict(R.TINY_DIMS)
-    sd_np = W.synthetic_state_dict(dims, seed=5)
+    sd_np = W.synthetic_state_dict(dims, seed=5, matrix_gain=gain)
     ctx = pkg.binding.Context(dims)
-    ctx.init_synthetic(5)
+    ctx.init_synthetic(5, matrix_gain=gain)
     ctx.finalize()
     for name, shape, kind in W.tensor_specs(dims):
         got = ctx.get_tensor(name, shape)
@@ -96,6 +99,11 @@ def test_device_synthetic_generator_is_bit_identical(pkg):
             assert np.abs(got - sd_np[name]).max() <= 1e-6, name
         else:
             assert np.array_equal(got, sd_np[name]), name
+    if gain != 1.0:
+        plain = W.synthetic_state_dict(dims, seed=5)
+        assert np.array_equal(sd_np["decoder.positional_embedding"], plain["decoder.positional_embedding"])
+        assert np.array_equal(sd_np["decoder.blocks.0.mlp.0.bias"], plain["decoder.blocks.0.mlp.0.bias"])
+        assert np.abs(sd_np["decoder.blocks.0.mlp.0.weight"]).max() > 2 * np.abs(plain["decoder.blocks.0.mlp.0.weight"]).max()
     ctx.close()
 
 
@@ -1167,10 +1175,12 @@ def test_decode_policy_at_the_production_vocabulary(pkg, model, TS):
     ctx.close()
 
 
-@pytest.mark.parametrize("model,d,heads", [("small", 768, 12), ("medium", 1024, 16)])
+@pytest.mark.parametrize("model,d,heads", [("small", 768, 12), ("medium", 1024, 16), ("d640", 640, 10), ("d576", 576, 9)])
 def test_decode_groups_above_sixteen_at_d768_and_d1024(pkg, model, d, heads):
     """at d = 768 (whisper-small, the reference's model) and d = 1024 the fc2 product splits K over
-    16 waves; with more than 16 rows its launch shape was rejected (WM_ERR_INVALID on every decode step).  One decode step
+    16 waves; with more than 16 rows its launch shape was rejected (WM_ERR_INVALID on every decode step).  ADVICE r3: the
+    widths whose K = 4d splits over <= 8 waves with MORE than 8 k-steps each (d = 640: 8 x 10, d = 576: 6 x 12) hit the same
+    rejection through the two-block shape; wm_create accepts them, so they must decode.  One decode step
     at 17 / 32 rows (wm_detect_language) and KV-cached greedy in groups of 17 / 18 (a 52-chunk call over three lanes)
     against the same chunks decoded in a group of 7, plus the oracle on the small group."""
     import torch
@@ -1265,6 +1275,13 @@ def test_early_stop_equals_truncation_and_cuts_the_work(lively, pkg):
         ctx.transcribe_greedy(base, prompt, NEW)
     with pytest.raises(pkg.binding.WhisperError, match="< 1"):
         ctx.set_token_budgets([0])
+    # budgets are consumed by the NEXT call even when that call fails validation -- they must not stay armed and
+    # silently truncate a later call that happens to have the same B
+    ctx.set_token_budgets([2] * 7)
+    with pytest.raises(pkg.binding.WhisperError, match="context"):
+        ctx.transcribe_greedy(base, prompt, 446)             # prompt + new tokens do not fit: fails before decoding
+    again, lens_again = ctx.transcribe_greedy(base, prompt, NEW, eot=-1)
+    assert np.all(lens_again == NEW) and np.array_equal(again, full7)
     # timestamp rules + suppress lists + early stop together (the rule state of a finished row is simply not used)
     TS, EOT = 900, 890
     ctx.set_suppress(list(range(EOT + 1, TS)), [EOT])
@@ -1311,4 +1328,60 @@ def test_early_stop_decode_time_follows_the_longest_live_sequence(pkg):
     assert t_short <= 0.25 * t_full, (t_short, t_full)          # 23 positions (+ <= 2 bursts of slack) instead of 203
     assert t_strag <= 0.80 * t_full, (t_strag, t_full)          # weights still stream, 23 of 24 cache streams do not
     ctx.dev_free(dp)
+    ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 4: the TIMED workload itself against the oracle, at its own size
+def test_timed_workload_against_the_oracle_at_its_own_size(pkg):
+    """bench.py's timed region decodes large-v2 at FULL depth in decode groups of 56 rows (7 batches of 8), 224 new tokens
+    after a 4-token prompt (228 positions), with 8-position burst graphs, three groups in flight.  Until round 3 no decode
+    position beyond ~20 had been compared with the oracle at production width, and never in a multi-block group.  Here:
+    the `lively` random-init model (matrix gain 4: tokens depend on the audio and on the history), one decode group of 56
+    rows (8 distinct chunks tiled 7 times) on ONE lane and the same chunks inside a 168-row call on THREE lanes; the rows
+    must be pairwise distinct per chunk, identical across the copies of a chunk and across the two calls, and ALL 224
+    choices of three distinct rows must be (within the scaled margin) the fp32 oracle's arg-max, teacher-forced on the GPU's
+    own prefix.  Measured margins are printed (profiles/r04_parity_margins.txt holds a run's figures)."""
+    import torch
+    dims = pkg.binding.MODEL_DIMS["large-v2"]
+    ctx = pkg.binding.Context(dims)
+    ctx.init_synthetic(20240928, matrix_gain=LIVELY_GAIN)       # bench.py's weights
+    _perturb_ln_on_device(ctx, dims, seed=8)
+    ctx.finalize()
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    base = np.stack([tone_chunk(i) if i % 2 else L.synth_chunk(60 + i) for i in range(8)])
+    prompt = [50258, 50259, 50359, 50363]
+    NEW = dims["n_text_ctx"] // 2                                # 224, openai-whisper's sample_len
+    idx56 = [i % 8 for i in range(56)]
+    ctx.set_lanes(1)
+    t56, l56 = ctx.transcribe_greedy(base[idx56], prompt, NEW, eot=-1)   # ONE decode group of 56 rows (4 batch blocks)
+    ctx.set_lanes(0)
+    assert t56.shape == (56, NEW) and np.all(l56 == NEW)
+    rows = t56[:8]
+    assert len({r.tobytes() for r in rows}) == 8, "the 8 chunks must decode to pairwise distinct token rows"
+    n_distinct = [len(set(r.tolist())) for r in rows]
+    changes = [int((r[1:] != r[:-1]).sum()) for r in rows]
+    print("distinct tokens per row", n_distinct, "token changes per row", changes)
+    assert min(n_distinct) >= 8 and min(changes) >= 16, (n_distinct, changes)   # history-dependent, not a fixed point
+    assert np.array_equal(t56, rows[idx56])                      # every copy of a chunk, in every batch block
+    idx168 = [(5 * i + 3) % 8 for i in range(168)]               # three lanes x 56 rows, other row positions
+    t168, l168 = ctx.transcribe_greedy(base[idx168], prompt, NEW, eot=-1)
+    assert np.array_equal(t168, rows[idx168]) and np.all(l168 == NEW)
+    # teacher-forced oracle on three distinct rows (a tone chunk, two noise chunks) x ALL 224 positions
+    sd = _oracle_weights(ctx, dims)
+    pick = [1, 2, 4]
+    mel = ctx.logmel(base[pick])
+    xa = ctx.encode_mel(mel)
+    worst = _check_greedy_against_teacher_forced_oracle(sd, dims, xa, prompt, rows[pick], scaled=True)
+    # the values too: GPU teacher-forced logits (stateless full-prefix path) vs the oracle over the whole 228-token prefix
+    seq = np.concatenate([np.tile(np.asarray(prompt, np.int32), (1, 1)), rows[pick[:1]]], axis=1)[:, :-1].astype(np.int32)
+    ref = R.decode_logits(sd, dims, seq, xa[:1]).numpy()
+    got = ctx.decode_logits(seq, xa[:1])
+    e_all = R.rel_l2(got, ref)
+    e_tail = R.rel_l2(got[:, -32:], ref[:, -32:])
+    agree = float((got[0].argmax(axis=1) == ref[0].argmax(axis=1)).mean())
+    print("large-v2 full depth, lively, 56-row group x 224 tokens: worst greedy gap %.3g logit (rms %.2f); teacher-forced "
+          "logits rel-L2 %.3e over 227 positions, %.3e over the last 32; arg-max agreement %.3f"
+          % (worst, float(np.sqrt((ref.astype(np.float64) ** 2).mean())), e_all, e_tail, agree))
+    assert e_all <= LOGIT_TOL and e_tail <= LOGIT_TOL, (e_all, e_tail)
     ctx.close()
