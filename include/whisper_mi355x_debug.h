@@ -69,6 +69,12 @@ WM_API int wmdbg_bench_gemm(wm_ctx *ctx, int M, int N, int K, int epi, int iters
  * Process-wide; used by the parity tests and A/B probes to run every shape through both kernels. */
 WM_API int wmdbg_set_gemm_tile(int tile);
 
+/* Launch-shape experiment knobs (csrc/wm_internal.h, struct WmTuning), by name: "gemv_tn", "gemv_nblk", "gemv_no_ppw2",
+ * "prefetch_max_b", "xattn_split_below", "xattn_wgs", "xattn_no_flat", "xattn_lds_pad", "xattn_splits", "gemm_tile",
+ * "gemm_gm", "no_early_stop"; key "reset" restores the product's rules.  Process-wide.  The PRODUCT library has no such
+ * entry point and reads no environment variable for launch shapes (rounds 1-3 had WM_GEMV_*, WM_XATTN_*, WM_GEMM_*). */
+WM_API int wmdbg_set_tuning(const char *key, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,8 @@
 #include "wm_internal.h"
 #include "model.h"
 
+WmTuning g_wm_tuning;   // wm_internal.h: defaults = the product; only the debug library has a setter
+
 // ---------------------------------------------------------------- errors -------------
 static thread_local std::string g_last_error;
 

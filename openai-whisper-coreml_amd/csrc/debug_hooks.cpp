@@ -15,6 +15,23 @@
 int wm_gemm_set_tile_override(int tile);
 extern "C" int wmdbg_set_gemm_tile(int tile) { return wm_gemm_set_tile_override(tile); }
 
+// The launch-shape experiment knobs (wm_internal.h WmTuning): by name, so that tools/ scripts need no struct mirror.
+extern "C" int wmdbg_set_tuning(const char *key, int value) {
+    WM_REQUIRE(key, WM_ERR_INVALID, "wmdbg_set_tuning: null key");
+    struct { const char *name; int *field; } table[] = {
+        {"gemv_tn", &g_wm_tuning.gemv_tn}, {"gemv_nblk", &g_wm_tuning.gemv_nblk}, {"gemv_no_ppw2", &g_wm_tuning.gemv_no_ppw2},
+        {"prefetch_max_b", &g_wm_tuning.prefetch_max_b}, {"xattn_split_below", &g_wm_tuning.xattn_split_below},
+        {"xattn_wgs", &g_wm_tuning.xattn_wgs}, {"xattn_no_flat", &g_wm_tuning.xattn_no_flat},
+        {"xattn_lds_pad", &g_wm_tuning.xattn_lds_pad}, {"xattn_splits", &g_wm_tuning.xattn_splits},
+        {"gemm_tile", &g_wm_tuning.gemm_tile}, {"gemm_gm", &g_wm_tuning.gemm_gm}, {"no_early_stop", &g_wm_tuning.no_early_stop},
+    };
+    if (strcmp(key, "reset") == 0) { g_wm_tuning = WmTuning(); return WM_OK; }
+    for (auto &e : table)
+        if (strcmp(key, e.name) == 0) { *e.field = value; return WM_OK; }
+    wm_set_error("wmdbg_set_tuning: unknown key '%s'", key);
+    return WM_ERR_INVALID;
+}
+
 extern "C" int wmdbg_mel_filterbank(int n_mels, float *out) {
     WM_REQUIRE(out && n_mels > 0 && n_mels <= 256, WM_ERR_INVALID, "bad args");
     std::vector<float> f;

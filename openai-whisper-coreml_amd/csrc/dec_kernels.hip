@@ -1015,16 +1015,11 @@ int wm_dec_gemv_split(int K, int *spw) {
 // L2 warm-up of the NEXT launch's weight matrix by extra workgroups of the current one: a latency lever for a decode
 // group of one batch block (the next GEMV finds its weights in L2: ~1 us off a 4-5 us launch).  Larger groups are
 // throughput-bound and run beside other groups; there the extra workgroups only take slots and bandwidth (measured,
-// 3 groups of 56 chunks: 1978 -> 2007 audio-s/s without).  WM_PREFETCH_MAX_B overrides the threshold, WM_NO_PREFETCH: off.
-static bool pf_enabled(int B) {
-    static const bool no_pf = getenv("WM_NO_PREFETCH") != nullptr;
-    static const int max_b = getenv("WM_PREFETCH_MAX_B") ? atoi(getenv("WM_PREFETCH_MAX_B")) : 16;
-    return !no_pf && B <= max_b;
-}
+// 3 groups of 56 chunks: 1978 -> 2007 audio-s/s without).  (g_wm_tuning: probes only, see wm_internal.h.)
+static bool pf_enabled(int B) { return B <= g_wm_tuning.prefetch_max_b; }
 
 static void pick_shape(int epi, bool ln, int spw, int nw, int B, int n_tiles, int *tn, int *nblk) {
-    static const int env_tn = getenv("WM_GEMV_TN") ? atoi(getenv("WM_GEMV_TN")) : 0;
-    static const int env_nb = getenv("WM_GEMV_NBLK") ? atoi(getenv("WM_GEMV_NBLK")) : 0;
+    const int env_tn = g_wm_tuning.gemv_tn, env_nb = g_wm_tuning.gemv_nblk;   // 0 in the product
     const int blocks = (B + 15) / 16;
     *tn = 1;
     *nblk = 1;
@@ -1082,7 +1077,7 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     // the 16-part K = 4d residual product at more than one batch block: two parts per wave, 8-wave workgroups (two per
     // CU).  pick_shape keeps every 16-wave split at one (tile, block) unit per workgroup, which is what the two-part
     // kernel is built for (d = 768 / 1024 / 1280: spw = 6 / 8 / 10).
-    static const bool no_ppw = getenv("WM_GEMV_NO_PPW2") != nullptr;
+    const bool no_ppw = g_wm_tuning.gemv_no_ppw2 != 0;
     const int ppw = (!no_ppw && !ln && a.epi == DE_RESID && nw == 16 && a.B > 16 && spw >= 6 && spw <= 10 && tn == 1 &&
                      nblk == 1) ? 2 : 1;
     p.n_tg = (p.n_tiles + tn - 1) / tn;
@@ -1144,12 +1139,11 @@ int wm_dec_embed(wm_ctx *ctx, const int *seq, const int *pos_ptr, int B, const b
 // Workgroups per (sequence, head) pair of the cross-attention: 1 when the pairs alone fill the chip, else the stream
 // set of a pair is dealt to 2, 4 or 8 workgroups.  A launch-shape choice: the arithmetic does not depend on it.
 int wm_dec_attn_splits(int B, int H) {
-    static const int env_thr = getenv("WM_XATTN_SPLIT_BELOW") ? atoi(getenv("WM_XATTN_SPLIT_BELOW")) : -1;
     const int bh = B * H;
     // few pairs: the (pair, stream) units are dealt flat over the chip and merged by a combine launch.  (Measured at
     // B = 8 x 20 heads = 160 pairs: flat 11.5 + combine 3.0 us vs 12.2 us for one 8-wave workgroup per pair -- the kernel
     // is bound by bytes in flight per CU, not by idle CUs -- so the split starts below 96 pairs only.)
-    const int thr = env_thr >= 0 ? env_thr : 96;
+    const int thr = g_wm_tuning.xattn_split_below;   // 96
     if (bh >= thr) return 1;
     int ns = 2;
     while (ns < 8 && bh * ns < 192) ns *= 2;
@@ -1169,9 +1163,8 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
         // 8 streams x 4 loads = 126 VGPRs: an 8-wave GEMV workgroup of another decode group fits beside one of these on a
         // CU (a second cross-attention workgroup does not: LDS reservation below); at most 256 workgroups -- one per CU --
         // walk the pairs, balanced (56 chunks x 20 heads = 224 workgroups x 5 pairs).  Measured alone at B = 8 / 56 / 128:
-        // 12.8 / 67 / 144 us (4.8 / 6.4 / 6.8 TB/s: ~6.4 is what HBM reads deliver).  WM_XATTN_WGS: workgroup cap (A/B).
-        static const int env_cap = getenv("WM_XATTN_WGS") ? atoi(getenv("WM_XATTN_WGS")) : 0;
-        const int cap = env_cap > 0 ? env_cap : 256;
+        // 12.8 / 67 / 144 us (4.8 / 6.4 / 6.8 TB/s: ~6.4 is what HBM reads deliver).
+        const int cap = g_wm_tuning.xattn_wgs > 0 ? g_wm_tuning.xattn_wgs : 256;
         int n_wg = B * H;
         if (n_wg > cap) {
             const int rounds = (n_wg + cap - 1) / cap;
@@ -1183,7 +1176,7 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
             tile_bytes = 16L * pf_k * 2;
             gx += pf_rows / 16;
         }
-        static const bool no_flat = getenv("WM_XATTN_NO_FLAT") != nullptr;
+        const bool no_flat = g_wm_tuning.xattn_no_flat != 0;
         if (nsplit > 1 && !no_flat) {
             // few pairs: deal the (pair, stream) units evenly over ~256 workgroups (see the kernel)
             const int units = B * H * 8;
@@ -1200,13 +1193,13 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
             // one beside it adds no bandwidth but fills the SIMDs' wave slots / VGPRs for the whole launch (persistent
             // workgroups), and the other groups' GEMVs -- which fit beside ONE such workgroup, LDS included (<= 66 KB) --
             // wait.  Measured, 3 groups in flight: 1920 -> 1966 audio-s/s (20 steps), 2014 -> 2118 (72 steps, decode stage
-            // 0.74 -> 0.79 of the HBM peak).  WM_XATTN_LDS_PAD=<bytes> overrides (0: off).
-            static const int lds_pad = getenv("WM_XATTN_LDS_PAD") ? atoi(getenv("WM_XATTN_LDS_PAD")) : 84 * 1024;
-            static std::atomic<bool> pad_set[64];  // per device (wm_multi: one process, every GPU of the node)
-            if (lds_pad > 0 && !pad_set[ctx->device & 63].load(std::memory_order_acquire)) {
+            // 0.74 -> 0.79 of the HBM peak).
+            const int lds_pad = g_wm_tuning.xattn_lds_pad;   // 84 KB
+            static std::atomic<int> pad_set[64];  // per device (wm_multi: one process, every GPU of the node): the size allowed so far
+            if (lds_pad > pad_set[ctx->device & 63].load(std::memory_order_acquire)) {
                 WM_HIP(hipFuncSetAttribute((const void *)dec_rows_attn_kernel<8, 4, WM_XATTN_NT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad));
-                pad_set[ctx->device & 63].store(true, std::memory_order_release);
+                pad_set[ctx->device & 63].store(lds_pad, std::memory_order_release);
             }
             dec_rows_attn_kernel<8, 4, WM_XATTN_NT><<<grid, (8 / nsplit) * 64, nsplit == 1 ? lds_pad : 0, ctx->stream>>>(
                 q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, nsplit, B * H, n_wg, (const char *)pf_ptr,

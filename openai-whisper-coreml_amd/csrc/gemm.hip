@@ -606,11 +606,10 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
 
 }  // namespace
 
-static int g_gemm_tile_override = 0;
 // A/B and parity probes force one of the two tile shapes (the wmdbg_set_gemm_tile hook lives in debug_hooks.cpp)
 int wm_gemm_set_tile_override(int tile) {
     if (tile != 0 && tile != 128 && tile != 256) return WM_ERR_INVALID;
-    g_gemm_tile_override = tile;
+    g_wm_tuning.gemm_tile = tile;
     return WM_OK;
 }
 
@@ -630,9 +629,8 @@ int wm_gemm(wm_ctx *ctx, const GemmArgs &g) {
     p.M = g.M; p.N = g.N; p.K = g.K; p.pos = g.pos; p.vt = g.vt;
     p.d_model = g.d_model; p.n_head = g.n_head; p.seq = g.seq; p.seq_pad = g.seq_pad; p.batch = g.batch;
     // Tile choice: the 256 x 256 staggered-phase kernel once it can put a workgroup on most CUs (one per CU);
-    // the 128 x 128 kernel (two per CU) for everything smaller.  WM_GEMM_TILE=128|256 forces one (tests, A/B).
-    static const int env_tile0 = getenv("WM_GEMM_TILE") ? atoi(getenv("WM_GEMM_TILE")) : 0;
-    const int env_tile = g_gemm_tile_override ? g_gemm_tile_override : env_tile0;
+    // the 128 x 128 kernel (two per CU) for everything smaller.  (g_wm_tuning.gemm_tile: the debug library's tests / probes.)
+    const int env_tile = g_wm_tuning.gemm_tile;
     const long tiles256 = (long)((g.M + BM2 - 1) / BM2) * ((g.N + BN2 - 1) / BN2);
     bool big = g.K >= 2 * BK && tiles256 >= 160;
     if (env_tile == 128) big = false;
@@ -641,8 +639,7 @@ int wm_gemm(wm_ctx *ctx, const GemmArgs &g) {
     p.tiles_m = (g.M + bm - 1) / bm;
     p.tiles_n = (g.N + bn - 1) / bn;
     const int grid = p.tiles_m * p.tiles_n;
-    static const int env_gm = getenv("WM_GEMM_GM") ? atoi(getenv("WM_GEMM_GM")) : 0;
-    p.group_m = env_gm > 0 ? env_gm : 4;  // measured at large-v2, B = 8: GM 1 / 4 / 8 / 16 -> fc1 341 / 328 / 335 / 335 us
+    p.group_m = g_wm_tuning.gemm_gm > 0 ? g_wm_tuning.gemm_gm : 4;  // measured at large-v2, B = 8: GM 1 / 4 / 8 / 16 -> fc1 341 / 328 / 335 / 335 us
     static const char *names[] = {"gemm_bias_bf16", "gemm_gelu_bf16", "gemm_resid_f32", "gemm_conv2_f32",
                                   "gemm_qkv_enc", "gemm_xkv", "gemm_f32"};
     WmProfScope ps(&ctx->prof, names[g.epi], ctx->stream);

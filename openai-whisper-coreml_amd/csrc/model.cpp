@@ -575,8 +575,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
     const wm_dims &D = m->dims;
     const int d = D.n_text_state, H = D.n_text_head, T = D.n_text_ctx, S = 1500;
     const int ns = wm_dec_attn_splits(B, H);
-    static const int env_xns = getenv("WM_XATTN_SPLITS") ? atoi(getenv("WM_XATTN_SPLITS")) : 0;  // A/B probe
-    const int xns = env_xns > 0 ? env_xns : ns;
+    const int xns = g_wm_tuning.xattn_splits > 0 ? g_wm_tuning.xattn_splits : ns;   // 0 in the product
     const int *live = m->stop_on ? m->dlive : nullptr, *nlive = m->stop_on ? m->dnlive : nullptr;
     // mean-centring offsets of the bf16 residual copy: the embedding wrote buffer 0; every LayerNorm-folded GEMV reads
     // the current buffer and leaves the new means in the other one

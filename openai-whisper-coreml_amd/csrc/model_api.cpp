@@ -536,7 +536,7 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
                "token budgets were set for %d chunks, the call has %d", (int)budgets.size(), B);
     for (auto &b : budgets) b = b > max_new ? max_new : b;
     static const bool no_graph = getenv("WM_NO_GRAPH") != nullptr;
-    static const bool no_stop = getenv("WM_NO_EARLY_STOP") != nullptr;   // A/B: decode every position, truncate on the host
+    const bool no_stop = g_wm_tuning.no_early_stop != 0;   // probes only: decode every position, truncate on the host
     const bool use_graph = !no_graph && !ctx->prof.on;
     StopCfg stop;
     stop.on = !no_stop && (eot >= 0 || !budgets.empty());

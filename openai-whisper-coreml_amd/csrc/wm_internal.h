@@ -139,3 +139,25 @@ struct wm_ctx {
 };
 
 int wm_ctx_make_current(const wm_ctx *ctx);
+
+// ---------------------------------------------------------------- launch-shape experiment knobs
+// Launch shapes are chosen by fixed rules (dec_kernels.hip pick_shape / wm_dec_attn_splits, gemm.hip wm_gemm): the
+// product library reads NO environment variable for them, so nothing outside the process's own calls can change a launch
+// shape in a library whose contract is bit-level batch invariance.  The A/B probes of tools/ change these fields through
+// wmdbg_set_tuning(), which exists in libwhisper_mi355x_dbg.so only (debug_hooks.cpp).  A value of 0 / the default below
+// means "the product's rule".
+struct WmTuning {
+    int gemv_tn = 0;              // force tiles per workgroup of the wide decode GEMVs (1, 2, 4)
+    int gemv_nblk = 0;            // 1: one batch block per workgroup also above 16 rows
+    int gemv_no_ppw2 = 0;         // 1: K = 4d residual product as 16-wave workgroups (no two-parts-per-wave kernel)
+    int prefetch_max_b = 16;      // L2 warm-up workgroups up to this decode-group size (0: never)
+    int xattn_split_below = 96;   // (sequence, head) pairs below which the cross-attention streams are dealt flat
+    int xattn_wgs = 256;          // workgroup cap of the cross-attention
+    int xattn_no_flat = 0;        // 1: split launches as (pair, split) grids instead of the flat deal
+    int xattn_lds_pad = 84 * 1024;  // dynamic LDS reserved per cross-attention workgroup (one per CU chip-wide); 0: off
+    int xattn_splits = 0;         // force the split count of the cross-attention (1, 2, 4, 8)
+    int gemm_tile = 0;            // force the encoder GEMM tile (128 / 256)
+    int gemm_gm = 4;              // grouped tile order of the encoder GEMM
+    int no_early_stop = 0;        // 1: decode every position and truncate on the host (the round-2 behaviour)
+};
+extern WmTuning g_wm_tuning;   // api.cpp

@@ -45,6 +45,23 @@ def test_product_library_exports_only_the_public_header(pkg):
     assert any(n.startswith("wmdbg_") for n in _exported(pkg.binding.DEBUG_LIB_PATH))
 
 
+def test_product_reads_only_its_documented_environment_variables():
+    """no launch-shape A/B switch in the product.  The translation units of libwhisper_mi355x.so may read
+    the run-time configuration INTEGRATION.md lists and nothing else; the probes' knobs live behind wmdbg_set_tuning
+    (debug_hooks.cpp, libwhisper_mi355x_dbg.so only)."""
+    csrc = os.path.join(ROOT, "openai-whisper-coreml_amd", "csrc")
+    allowed = {"WM_DEVICE", "WM_LANES", "WM_BURST", "WM_NO_GRAPH", "WM_RCCL_PATH"}
+    seen = set()
+    for f in sorted(os.listdir(csrc)):
+        if f == "debug_hooks.cpp" or not f.endswith((".cpp", ".hip", ".h")):
+            continue
+        seen |= set(re.findall(r'getenv\(\s*"([A-Za-z0-9_]+)"', open(os.path.join(csrc, f)).read()))
+    assert seen <= allowed, sorted(seen - allowed)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name in sorted(seen):
+        assert name in doc, "%s is read by the product but not documented in INTEGRATION.md" % name
+
+
 def test_library_does_not_link_the_oracle(pkg):
     import subprocess
     out = subprocess.run(["readelf", "-d", pkg.binding.LIB_PATH], capture_output=True, text=True).stdout

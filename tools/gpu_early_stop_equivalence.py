@@ -1,7 +1,7 @@
 """GPU check at production scale: early stop == decode everything and truncate.  large-v2 at FULL depth, one decode group
 of 56 chunks and a 168-chunk call (three lanes), per-chunk budgets uniform(8..60): the same process decodes with the stop
-machinery ON; a child process with WM_NO_EARLY_STOP=1 decodes every position and truncates on the host (the round-2
-behaviour); tokens and lengths must be identical.  Prints the decode times of both."""
+machinery ON; a child process on the DEBUG library with wmdbg_set_tuning("no_early_stop", 1) decodes every position and
+truncates on the host (the round-2 behaviour); tokens and lengths must be identical.  Prints the decode times of both."""
 import os
 import subprocess
 import sys
@@ -15,7 +15,11 @@ def run(tag):
     import openai_whisper_coreml_amd as pkg
     B = pkg.binding
     dims = B.MODEL_DIMS["large-v2"]
-    ctx = B.Context(dims)
+    ctx = B.Context(dims, debug=(tag == "truncate"))
+    if tag == "truncate":
+        import ctypes
+        ctx.lib.wmdbg_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        assert ctx.lib.wmdbg_set_tuning(b"no_early_stop", 1) == 0
     ctx.init_synthetic(20240928)
     ctx.finalize()
     prompt = [50258, 50259, 50359, 50363]
@@ -37,8 +41,7 @@ if __name__ == "__main__":
         run(sys.argv[1])
     else:
         run("early_stop")
-        env = dict(os.environ, WM_NO_EARLY_STOP="1")
-        subprocess.run([sys.executable, __file__, "truncate"], check=True, env=env)
+        subprocess.run([sys.executable, __file__, "truncate"], check=True)
         a, b = np.load("/tmp/es_early_stop.npz"), np.load("/tmp/es_truncate.npz")
         for k in a.files:
             assert np.array_equal(a[k], b[k]), k
