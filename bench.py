@@ -70,6 +70,101 @@ def algorithmic_work(family, dims, B):
     return None, 0.0
 
 
+def family_source_sha256(family):
+    """sha256 of the kernel source file that implements a kernel family: profiles/pmc_traffic.json stores it with every
+    PMC figure, so that a figure taken on another version of the kernel is reported as null instead of going stale."""
+    import hashlib
+    f = ("dec_kernels.hip" if family.startswith(("dec_", "argmax")) else "gemm.hip" if family.startswith("gemm_")
+         else "frontend.hip" if family.startswith("logmel") else "enc_kernels.hip")
+    try:
+        return f, hashlib.sha256(open(os.path.join(ROOT, "openai-whisper-coreml_amd", "csrc", f), "rb").read()).hexdigest()
+    except OSError:
+        return f, None
+
+
+def _stage_work(dims, nb, n_prompt, max_new, mean_grp_steps):
+    """Algorithmic work of ONE step (= nb chunks) per stage (SURVEY.md 8d formulas): front-end bytes, encoder + cross-K/V
+    flops, decode bytes (the decoder weights are streamed once per decode group of mean_grp_steps steps and position)."""
+    d, L, V = dims["n_text_state"], dims["n_text_layer"], dims["n_vocab"]
+    da, La, nm = dims["n_audio_state"], dims["n_audio_layer"], dims["n_mels"]
+    dec_steps = n_prompt + max_new - 1
+    fe_bytes = nb * (480000 * 2 + nm * 3000 * 4)
+    enc_flops = nb * (2.0 * 3000 * da * nm * 3 + 2.0 * 1500 * da * da * 3
+                      + La * (8.0 * 1500 * da * da + 4.0 * 1500 * 1500 * da + 16.0 * 1500 * da * da))
+    xkv_flops = nb * L * 4.0 * 1500 * d * d
+    t_mean = (n_prompt + max_new) / 2.0
+    dec_bytes = dec_steps * (2.0 * (L * 14 * d * d + V * d) / mean_grp_steps + nb * L * 2 * 1500 * d * 2 + nb * L * 2 * t_mean * d * 2)
+    return fe_bytes, enc_flops + xkv_flops, dec_bytes, dec_steps
+
+
+def stage_rooflines(dims, nb, n_prompt, max_new, mean_grp_steps, stage_s):
+    """Per-stage algorithmic work (per GPU per step) against the roofline that bounds the stage: front end and decode =
+    HBM bytes, encoder + cross-K/V = bf16 MFMA flops.  stage_s: seconds per step of the three stages."""
+    fe_bytes, flops, dec_bytes, dec_steps = _stage_work(dims, nb, n_prompt, max_new, mean_grp_steps)
+    out = {}
+    if stage_s[0] > 0:
+        a = fe_bytes / stage_s[0] / 1e9
+        out["frontend"] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS}
+    if stage_s[1] > 0:
+        a = flops / stage_s[1] / 1e12
+        out["encoder_xkv"] = {"bound": "mfma", "achieved": a, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                              "frac": a / MFMA_BF16_PEAK_TF}
+    if stage_s[2] > 0:
+        a = dec_bytes / stage_s[2] / 1e9
+        out["decode"] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                         "bytes_per_position": dec_bytes / dec_steps}
+    return out
+
+
+def step_roofline(dims, nb, n_prompt, max_new, mean_grp_steps, step_s):
+    """Whole step against the sum of its stages' rooflines: HBM time of the front end and of the decode bytes at
+    8 TB/s plus MFMA time of the encoder + cross-K/V flops at 2.5 PFLOP/s, over the measured wall time per step."""
+    fe_bytes, flops, dec_bytes, _ = _stage_work(dims, nb, n_prompt, max_new, mean_grp_steps)
+    bound_s = (fe_bytes + dec_bytes) / (HBM_PEAK_GBS * 1e9) + flops / (MFMA_BF16_PEAK_TF * 1e12)
+    return {"bound_ms": bound_s * 1e3, "measured_ms": step_s * 1e3, "frac": bound_s / step_s,
+            "hbm_bytes": fe_bytes + dec_bytes, "mfma_flops": flops}
+
+
+def other_configs(B, main_model, pcm16, max_new=224):
+    """The other BASELINE.json configurations on this GPU, a few seconds each: tiny.en single chunk
+    (configs[1], latency), base batch 32 as one decode group (configs[2]), large-v3 15 chunks as one group (the per-GPU
+    shard of configs[4]: 1 h = 120 chunks over 8 GPUs; `--model large-v3 --total-chunks 120 --gpus 8` is that job itself).
+    Same weights recipe, same fixed-length greedy decode; every entry: audio-s/s of the call, its stage split (HIP events
+    inside the library) and the stage rooflines."""
+    out = {}
+    cases = [("tiny.en_b1_latency", "tiny.en", 1, 3), ("base_b32_one_group", "base", 32, 2),
+             ("large-v3_15_chunks_one_group", "large-v3", 15, 2)]
+    for key, model, nb, reps in cases:
+        try:
+            dims = B.MODEL_DIMS[model]
+            c = B.Context(dims)
+            c.init_synthetic(20240928, matrix_gain=4.0)
+            c.finalize()
+            c.set_lanes(1)
+            prompt = [50258, 50259, 50359, 50363] if dims["n_vocab"] >= 51865 else [50257, 50362]
+            dp = c.to_device(pcm16[np.arange(nb) % len(pcm16)])
+            best, stage = None, None
+            for i in range(reps + 1):                      # first call: graph capture, allocations
+                t0 = time.perf_counter()
+                toks, _ = c.transcribe_greedy(dp, prompt, max_new, eot=-1, mem=B.WM_MEM_DEVICE, pcm_dtype=B.WM_I16, B=nb)
+                dt = time.perf_counter() - t0
+                if i > 0 and (best is None or dt < best):
+                    best, stage = dt, np.array(c.last_stage_ms(), dtype=np.float64) / 1e3
+            out[key] = {"model": model, "chunks": nb, "value": 30.0 * nb / best, "unit": "audio-sec/s",
+                        "ms_per_step": best * 1e3, "decoder_tok_per_s": nb * max_new / max(stage[2], 1e-9),
+                        "decoder_ms_per_position": stage[2] * 1e3 / (len(prompt) + max_new - 1),
+                        "stage_ms": {"frontend": stage[0] * 1e3, "encoder_xkv": stage[1] * 1e3, "decode": stage[2] * 1e3},
+                        "stage_roofline": stage_rooflines(dims, nb, len(prompt), max_new, 1.0, stage),
+                        "step_roofline": step_roofline(dims, nb, len(prompt), max_new, 1.0, best),
+                        "distinct_token_rows": len({r.tobytes() for r in toks}),
+                        "timing": "min of %d calls after one warm-up call, one decode group on one lane" % reps}
+            c.dev_free(dp)
+            c.close()
+        except Exception as e:   # never take the headline down
+            out[key] = {"model": model, "chunks": nb, "value": None, "error": repr(e)}
+    return out
+
+
 def effective_cores():
     """Host cores this process may actually use (affinity mask and cgroup CPU quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -221,6 +316,11 @@ def main():
                     help="matrix gain of the random-init weights (wm_init_synthetic_gain): 4 = the `lively` model whose tokens "
                          "depend on the audio and on the decode history, so that the token cross-checks below can fail; "
                          "1 = plain N(0, 0.02^2) (a nearly input-independent model).  Timing does not depend on it.")
+    ap.add_argument("--total-chunks", type=int, default=0,
+                    help="STRONG scaling: the job is this many 30 s chunks in total, block-partitioned over the ranks "
+                         "(sharding.partition: 120 chunks = 1 h -> 15 per GPU at 8 GPUs, BASELINE.json configs[4]); a step "
+                         "is then one pass over the whole job and --batch is ignored.  Must be divisible by --gpus.")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other BASELINE.json configurations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-early-stop", action="store_true", help="skip the additional early-stop workload")
     ap.add_argument("--no-single-batch", action="store_true",
@@ -262,6 +362,11 @@ def main():
     ctx.finalize()
 
     nb = args.batch
+    if args.total_chunks > 0:
+        if args.total_chunks % world:
+            raise SystemExit("--total-chunks %d is not divisible by the %d ranks" % (args.total_chunks, world))
+        lo, hi = sharding.partition(args.total_chunks, world, rank)   # this rank's contiguous block of the recording
+        nb = hi - lo
     F = max(1, min(args.fuse, 128 // nb if nb <= 128 else 1))
     S = max(1, args.inflight)
     F = min(F, max(1, -(-args.steps // S)))   # few timed steps: smaller groups rather than idle lanes
@@ -446,8 +551,14 @@ def main():
             # HBM bytes per launch from the separate rocprofv3 --pmc FETCH_SIZE pass (profiles/), valid only for the
             # geometry it was taken on: keyed "<family>@<model>:B<group chunks>"
             t = traffic_db.get("%s@%s:B%d" % (dom, args.model, grp_chunks))
-            traffic = t["hbm_read_bytes_per_launch"] if t else None
-            common = {"kernel": dom, "group_chunks": grp_chunks, "traffic": traffic, "avg_us": avg_s * 1e6,
+            src_file, src_sha = family_source_sha256(dom)
+            fresh = bool(t) and src_sha is not None and t.get("kernel_source_sha256") == src_sha
+            traffic = t["hbm_read_bytes_per_launch"] if fresh else None
+            traffic_note = ("PMC pass of this build (%s)" % t.get("source", "profiles/") if fresh else
+                            "null: no PMC pass for this geometry" if not t else
+                            "null: the PMC pass on file was taken on another version of csrc/%s (sha256 differs)" % src_file)
+            common = {"kernel": dom, "group_chunks": grp_chunks, "traffic": traffic, "traffic_note": traffic_note,
+                      "avg_us": avg_s * 1e6,
                       "avg_us_events_raw": raw_us, "event_overhead_us": ev_over, "launches": prof[dom]["n"]}
             # IN SITU: the same family's mean launch duration in the TIMED configuration -- the same plan on all S lanes at
             # once (eager launches, every launch of every lane bracketed by events on its own stream).  `frac` above is the
@@ -486,6 +597,10 @@ def main():
                 roof = dict(common, bound="mfma", achieved=ach, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s",
                             frac=ach / MFMA_BF16_PEAK_TF, alg_flops_per_launch=work)
 
+    others = None
+    if rank == 0 and world == 1 and not args.no_other_configs and args.model == "large-v2" and args.steps > 0:
+        others = other_configs(B, args.model, pcm, max_new)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -493,46 +608,6 @@ def main():
         except Exception as e:  # the baseline leg must never take the GPU number down with it
             cpu = {"value": None, "unit": "audio-sec/s", "cores": os.cpu_count(), "kind": "port",
                    "sample": "failed: %r" % (e,)}
-
-    def stage_rooflines(stage_s, dec_steps):
-        """Per-stage algorithmic work (SURVEY.md 8d formulas, per GPU per step) against the roofline that
-        bounds the stage: front end and decode = HBM bytes, encoder + cross-K/V = bf16 MFMA flops."""
-        d, L, V, H = dims["n_text_state"], dims["n_text_layer"], dims["n_vocab"], dims["n_text_head"]
-        da, La, nm = dims["n_audio_state"], dims["n_audio_layer"], dims["n_mels"]
-        fe_bytes = nb * (480000 * 2 + nm * 3000 * 4)
-        enc_flops = nb * (2.0 * 3000 * da * nm * 3 + 2.0 * 1500 * da * da * 3
-                          + La * (8.0 * 1500 * da * da + 4.0 * 1500 * 1500 * da + 16.0 * 1500 * da * da))
-        xkv_flops = nb * L * 4.0 * 1500 * d * d
-        t_mean = (len(prompt) + max_new) / 2.0
-        # per step (= nb chunks): the weights are streamed once per decode group of F steps
-        dec_bytes = dec_steps * (2.0 * (L * 14 * d * d + V * d) / mean_grp_steps + nb * L * 2 * 1500 * d * 2 + nb * L * 2 * t_mean * d * 2)
-        out = {}
-        if stage_s[0] > 0:
-            a = fe_bytes / stage_s[0] / 1e9
-            out["frontend"] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS}
-        if stage_s[1] > 0:
-            a = (enc_flops + xkv_flops) / stage_s[1] / 1e12
-            out["encoder_xkv"] = {"bound": "mfma", "achieved": a, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                                  "frac": a / MFMA_BF16_PEAK_TF}
-        if stage_s[2] > 0:
-            a = dec_bytes / stage_s[2] / 1e9
-            out["decode"] = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
-                             "bytes_per_position": dec_bytes / dec_steps}
-        return out
-
-    def step_roofline(step_s, dec_steps):
-        """Whole step against the sum of its stages' rooflines: HBM time of the front end and of the decode bytes at
-        8 TB/s plus MFMA time of the encoder + cross-K/V flops at 2.5 PFLOP/s, over the measured wall time per step."""
-        d, L, V = dims["n_text_state"], dims["n_text_layer"], dims["n_vocab"]
-        da, La, nm = dims["n_audio_state"], dims["n_audio_layer"], dims["n_mels"]
-        fe_bytes = nb * (480000 * 2 + nm * 3000 * 4)
-        flops = nb * (2.0 * 3000 * da * nm * 3 + 2.0 * 1500 * da * da * 3
-                      + La * (8.0 * 1500 * da * da + 4.0 * 1500 * 1500 * da + 16.0 * 1500 * da * da)) + nb * L * 4.0 * 1500 * d * d
-        t_mean = (len(prompt) + max_new) / 2.0
-        dec_bytes = dec_steps * (2.0 * (L * 14 * d * d + V * d) / mean_grp_steps + nb * L * 2 * 1500 * d * 2 + nb * L * 2 * t_mean * d * 2)
-        bound_s = (fe_bytes + dec_bytes) / (HBM_PEAK_GBS * 1e9) + flops / (MFMA_BF16_PEAK_TF * 1e12)
-        return {"bound_ms": bound_s * 1e3, "measured_ms": step_s * 1e3, "frac": bound_s / step_s,
-                "hbm_bytes": fe_bytes + dec_bytes, "mfma_flops": flops}
 
     if rank == 0:
         total_audio = 30.0 * nb * world * args.steps
@@ -548,7 +623,7 @@ def main():
             "unit": "audio-sec/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_steps_run,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.total_chunks > 0 else "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "whisper-%s geometry, random-init weights, batches of %d x 30 s int16 chunks resident "
                                    "in HBM, greedy %d new tokens (EOT suppressed), prompt %d tokens; a step = one batch; "
@@ -557,7 +632,8 @@ def main():
                                    % (args.model, nb, max_new, len(prompt), F, grp_chunks, S),
                        "chunks_per_gpu": nb, "new_tokens": max_new, "decode_group_chunks": grp_chunks,
                        "decode_groups": sharding.plan_groups(args.steps, F, S),
-                       "inflight_batches_per_gpu": S * F, "parallelism": "chunk-dp%d" % world},
+                       "inflight_batches_per_gpu": S * F, "parallelism": "chunk-dp%d" % world,
+                       "total_chunks": args.total_chunks if args.total_chunks > 0 else None},
             "rtf": dt / total_audio,
             "decoder_tok_per_s": (S * nb * world * max_new) / max(stage_s[2], 1e-9),   # S pipelines decode concurrently
             "tok_per_s_end_to_end": (nb * world * max_new * args.steps) / dt,
@@ -576,8 +652,10 @@ def main():
             "decoder_ms_per_step": stage_s[2] * 1e3 / dec_steps,
             "stage_ms": {"frontend": stage_s[0] * 1e3, "encoder_xkv": stage_s[1] * 1e3, "decode": stage_s[2] * 1e3},
             "roofline": roof,
-            "stage_roofline": stage_rooflines(stage_s / S, dec_steps),   # S pipelines overlap: per-step share of wall time
-            "step_roofline": step_roofline(dt / args.steps, dec_steps),
+            # S pipelines overlap: per-step share of wall time
+            "stage_roofline": stage_rooflines(dims, nb, len(prompt), max_new, mean_grp_steps, stage_s / S),
+            "step_roofline": step_roofline(dims, nb, len(prompt), max_new, mean_grp_steps, dt / args.steps),
+            "other_configs": others,
             "roofline_note": "dominant kernel family of ONE decode group of the size the timed region ran (single lane, eager launches): mean launch duration from per-launch HIP events on the launch stream minus the event-bracketing bias calibrated on a kernel of known device-clock duration; the rocprofv3 --kernel-trace summary of the same single-lane command is in profiles/; traffic = 2 x FETCH_SIZE from a separate rocprofv3 --pmc pass (profiles/pmc_traffic.json), null when no pass exists for this geometry",
             "cpu_baseline": cpu,
             # per-family table of the single-lane, eager, event-bracketed pass (one group of grp_chunks chunks = grp_steps

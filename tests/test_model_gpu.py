@@ -1362,14 +1362,16 @@ def test_timed_workload_against_the_oracle_at_its_own_size(pkg):
     n_distinct = [len(set(r.tolist())) for r in rows]
     changes = [int((r[1:] != r[:-1]).sum()) for r in rows]
     print("distinct tokens per row", n_distinct, "token changes per row", changes)
-    assert min(n_distinct) >= 8 and min(changes) >= 16, (n_distinct, changes)   # history-dependent, not a fixed point
+    # history-dependent: most rows keep changing over the 224 positions (a random-init model may drive a chunk into a short
+    # cycle -- measured: two of the four noise chunks do, after ~3 tokens); the rows teacher-forced below are the liveliest
+    assert sum(c >= 16 for c in changes) >= 5 and sum(n >= 8 for n in n_distinct) >= 5, (n_distinct, changes)
     assert np.array_equal(t56, rows[idx56])                      # every copy of a chunk, in every batch block
     idx168 = [(5 * i + 3) % 8 for i in range(168)]               # three lanes x 56 rows, other row positions
     t168, l168 = ctx.transcribe_greedy(base[idx168], prompt, NEW, eot=-1)
     assert np.array_equal(t168, rows[idx168]) and np.all(l168 == NEW)
     # teacher-forced oracle on three distinct rows (a tone chunk, two noise chunks) x ALL 224 positions
     sd = _oracle_weights(ctx, dims)
-    pick = [1, 2, 4]
+    pick = sorted(int(i) for i in np.argsort(changes)[-3:])
     mel = ctx.logmel(base[pick])
     xa = ctx.encode_mel(mel)
     worst = _check_greedy_against_teacher_forced_oracle(sd, dims, xa, prompt, rows[pick], scaled=True)
