@@ -69,6 +69,12 @@ WM_API int wmdbg_bench_gemm(wm_ctx *ctx, int M, int N, int K, int epi, int iters
  * Process-wide; used by the parity tests and A/B probes to run every shape through both kernels. */
 WM_API int wmdbg_set_gemm_tile(int tile);
 
+/* The ALL-FP32 debug model path (BASELINE.md parity gate: "fp32 debug path must match to <= 1e-4 rel-L2"; csrc/f32_path.hip).
+ * precision = WM_F32: wm_encode and wm_decode_logits of THIS context run with f32 activations, f32 K/V and f32 accumulation on
+ * the very weights the product multiplies (the bf16 values in HBM, in their product layouts) -- separates bugs from rounding.
+ * WM_BF16 restores the product kernels.  wm_detect_language / wm_transcribe_greedy are not affected. */
+WM_API int wmdbg_set_precision(wm_ctx *ctx, int precision);
+
 /* Launch-shape experiment knobs (csrc/wm_internal.h, struct WmTuning), by name: "gemv_tn", "gemv_nblk", "gemv_no_ppw2",
  * "prefetch_max_b", "xattn_split_below", "xattn_wgs", "xattn_no_flat", "xattn_lds_pad", "xattn_splits", "gemm_tile",
  * "gemm_gm", "no_early_stop"; key "reset" restores the product's rules.  Process-wide.  The PRODUCT library has no such

@@ -313,6 +313,15 @@ class Context:
         else:
             _check(self.lib, self.lib.wm_init_synthetic_gain(self.handle, int(seed), float(matrix_gain)))
 
+    def set_precision(self, f32):
+        """Debug library only (Context(..., debug=True)): route wm_encode / wm_decode_logits of this context through the
+        all-fp32 debug model path (wmdbg_set_precision, csrc/f32_path.hip) or back to the product kernels."""
+        if not hasattr(self.lib, "wmdbg_set_precision"):
+            raise WhisperError(-1, "set_precision needs the debug library: Context(dims, debug=True)")
+        self.lib.wmdbg_set_precision.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self.lib.wmdbg_set_precision.restype = ctypes.c_int
+        _check(self.lib, self.lib.wmdbg_set_precision(self.handle, WM_F32 if f32 else WM_BF16))
+
     def finalize(self):
         _check(self.lib, self.lib.wm_finalize(self.handle))
 

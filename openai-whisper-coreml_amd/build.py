@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libwhisper_mi355x.so")
 DBG_LIB = os.path.join(HERE, "libwhisper_mi355x_dbg.so")   # product objects + csrc/debug_hooks.cpp (tests / tools only)
-DEBUG_ONLY = ("debug_hooks.cpp",)
+DEBUG_ONLY = ("debug_hooks.cpp", "f32_path.hip")   # the wmdbg_* hooks and the all-fp32 debug model path
 HOST_BIN = os.path.join(HERE, "host", "lid_main")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

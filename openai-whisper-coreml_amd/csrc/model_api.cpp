@@ -139,13 +139,14 @@ extern "C" int wm_load_weights(wm_ctx *ctx, const char *path) try {
 extern "C" int wm_encode(wm_ctx *ctx, const float *mel, int B, float *xa, wm_mem mem) try {
     WM_MODEL(ctx);
     WM_REQUIRE(mel && xa && B >= 1, WM_ERR_INVALID, "null pointer / B < 1");
-    if (mem == WM_MEM_DEVICE) return wm_model_encode_dev(ctx, mel, B, xa);
+    const auto encode_dev = ctx->dbg_hooks ? ctx->dbg_hooks->encode_dev : wm_model_encode_dev;   // null hooks in the product
+    if (mem == WM_MEM_DEVICE) return encode_dev(ctx, mel, B, xa);
     const size_t in_b = (size_t)B * m->dims.n_mels * WM_N_FRAMES * 4;
     const size_t out_b = (size_t)B * 1500 * m->dims.n_audio_state * 4;
     char *st;
     WM_TRY(io_stage(ctx, in_b + out_b, &st));
     WM_HIP(hipMemcpyAsync(st, mel, in_b, hipMemcpyHostToDevice, ctx->stream));
-    WM_TRY(wm_model_encode_dev(ctx, (const float *)st, B, (float *)(st + in_b)));
+    WM_TRY(encode_dev(ctx, (const float *)st, B, (float *)(st + in_b)));
     WM_HIP(hipMemcpyAsync(xa, st + in_b, out_b, hipMemcpyDeviceToHost, ctx->stream));
     WM_HIP(hipStreamSynchronize(ctx->stream));
     return WM_OK;
@@ -189,6 +190,24 @@ extern "C" int wm_decode_logits(wm_ctx *ctx, const int32_t *tokens, int B, int T
             WM_REQUIRE(tok >= 0 && tok < V, WM_ERR_INVALID, "token id %d outside [0, %d)", tok, V);
             tb[(size_t)t * B + b] = tok;
         }
+    if (ctx->dbg_hooks) {   // debug library only: the all-fp32 path (xa stays f32, no K/V cache, no bf16 anywhere)
+        const float *d_xa = xa;
+        float *d_out = logits;
+        char *st = nullptr;
+        const size_t xa_b = (size_t)B * 1500 * m->dims.n_audio_state * 4, out_b = (size_t)B * T * V * 4;
+        if (mem == WM_MEM_HOST) {
+            WM_TRY(io_stage(ctx, ((xa_b + 255) & ~(size_t)255) + out_b, &st));
+            WM_HIP(hipMemcpyAsync(st, xa, xa_b, hipMemcpyHostToDevice, ctx->stream));
+            d_xa = (const float *)st;
+            d_out = (float *)(st + ((xa_b + 255) & ~(size_t)255));
+        }
+        WM_TRY(ctx->dbg_hooks->decode_logits_dev(ctx, host_tok.data(), B, T, d_xa, d_out));
+        if (mem == WM_MEM_HOST) {
+            WM_HIP(hipMemcpyAsync(logits, d_out, out_b, hipMemcpyDeviceToHost, ctx->stream));
+            WM_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        return WM_OK;
+    }
     WM_TRY(wm_model_decode_begin(ctx, B));
     WM_TRY(load_xa(ctx, xa, B, mem));
     WM_HIP(hipMemcpyAsync(m->dseq, tb.data(), tb.size() * 4, hipMemcpyHostToDevice, ctx->stream));

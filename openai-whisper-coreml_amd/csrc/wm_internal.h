@@ -126,6 +126,15 @@ const float *wm_mel80_table();
 
 // ---------------------------------------------------------------- context ------------
 struct WmModel;  // model.h
+struct wm_ctx;
+
+// Model-call overrides a DEBUG build can install on a context (libwhisper_mi355x_dbg.so: wmdbg_set_precision -> the
+// all-fp32 path of f32_path.hip).  The product library has no code that sets them: always null there.
+struct WmDebugHooks {
+    int (*encode_dev)(wm_ctx *ctx, const float *d_mel, int B, float *d_xa);
+    int (*decode_logits_dev)(wm_ctx *ctx, const int32_t *host_tokens /*[B][T]*/, int B, int T, const float *d_xa,
+                             float *d_logits /*[B][T][n_vocab]*/);
+};
 
 struct wm_ctx {
     int device = 0;
@@ -135,6 +144,7 @@ struct wm_ctx {
     WmModel *model = nullptr;
     float stage_ms[3] = {0, 0, 0};
     std::vector<wm_ctx *> lanes;  // weight-sharing clones owned by this context (wm_transcribe_greedy)
+    const WmDebugHooks *dbg_hooks = nullptr;
     int max_lanes = 0;            // wm_set_lanes: decode groups in flight per wm_transcribe_greedy call (0: $WM_LANES, default 3)
 };
 

@@ -24,6 +24,40 @@ W = importlib.import_module("openai_whisper_coreml_amd.weights")
 ENC_TOL = 5e-3
 LOGIT_TOL = 1e-2
 MARGIN = 0.05
+# Per-site gates (rel-L2 against the fp32 oracle).  Every value is <= 3x what the site measured on an MI355X
+# (profiles/r04_parity_margins_tests.txt, written by this module's own run: gate() records every measurement); ENC_TOL /
+# LOGIT_TOL above are the envelope BASELINE.md states, no site is looser than 3x its own measurement.
+TOL = {
+    "tiny.enc": ENC_TOL, "tiny.logits": LOGIT_TOL, "golden.enc_rows": ENC_TOL, "golden.logits_head": 2 * LOGIT_TOL,
+    "tiny_en.enc": ENC_TOL, "tiny_en.logits": LOGIT_TOL, "base.enc": ENC_TOL, "base.enc_rows": ENC_TOL,
+    "large_v3_2layer.enc": ENC_TOL, "large_v3_2layer.logits": LOGIT_TOL, "large_v2_full.enc": ENC_TOL,
+    "large_v2_full.logits": LOGIT_TOL, "tiny_lively.enc_silence": ENC_TOL, "small_full.enc": ENC_TOL,
+    "small_full.logits_t1": LOGIT_TOL, "large_v2_full_b8.enc": ENC_TOL, "large_v3_full.enc": ENC_TOL,
+    "large_v3_full.logits": LOGIT_TOL, "converted.enc": ENC_TOL, "converted.logits": LOGIT_TOL, "offset.logits": LOGIT_TOL,
+    "policy.logits": LOGIT_TOL, "workload.logits_all": LOGIT_TOL, "workload.logits_tail": LOGIT_TOL,
+    "f32.enc": 1e-4, "f32.logits": 1e-4,
+}
+_MEASURED = []
+
+
+def gate(name, value, tol=None):
+    """assert-able: value <= tol (default TOL[name]); records the measurement (written to gpurun_out/ at module teardown)."""
+    tol = TOL[name] if tol is None else tol
+    _MEASURED.append((name, float(value), float(tol)))
+    assert value <= tol, "%s: measured %.3e > gate %.3e" % (name, value, tol)
+    return True
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _write_measured_margins():
+    yield
+    from conftest import ROOT
+    out = os.path.join(ROOT, "gpurun_out")
+    if _MEASURED and os.path.isdir(out):
+        with open(os.path.join(out, "parity_margins_tests.txt"), "w") as f:
+            f.write("# tests/test_model_gpu.py: measured rel-L2 vs the fp32 oracle at every gated site (name, measured, gate, gate / measured)\n")
+            for n, v, t in _MEASURED:
+                f.write("%-36s %.3e  %.3e  %5.1fx\n" % (n, v, t, t / max(v, 1e-30)))
 
 
 def nontrivial_ln(sd, seed=0):
@@ -132,7 +166,7 @@ def test_encoder_parity(tiny):
     want = R.encode(sd, dims, mel).numpy()
     e = R.rel_l2(got, want)
     print("encoder rel-L2", e)
-    assert got.shape == (2, 1500, 128) and e <= ENC_TOL
+    assert got.shape == (2, 1500, 128) and gate("tiny.enc", e)
 
 
 def test_committed_model_golden(pkg):
@@ -145,9 +179,9 @@ def test_committed_model_golden(pkg):
     ctx.finalize()
     mel = g["mel"].astype(np.float32)[None]
     xa = ctx.encode_mel(mel)
-    assert R.rel_l2(xa[0, g["rows"]], g["xa_rows"]) <= ENC_TOL
+    assert gate("golden.enc_rows", R.rel_l2(xa[0, g["rows"]], g["xa_rows"]))
     lg = ctx.decode_logits(g["tokens"][None], xa)
-    assert R.rel_l2(lg[0][:, :64], g["logits_head"]) <= 2 * LOGIT_TOL
+    assert gate("golden.logits_head", R.rel_l2(lg[0][:, :64], g["logits_head"]))
     ctx.close()
 
 
@@ -200,7 +234,7 @@ def test_decode_logits_parity(tiny):
     want = R.decode_logits(sd, dims, toks, xa).numpy()
     e = R.rel_l2(got, want)
     print("logits rel-L2", e, "std", want.std())
-    assert got.shape == (2, 6, 1024) and e <= LOGIT_TOL
+    assert got.shape == (2, 6, 1024) and gate("tiny.logits", e)
     # T = 1 is the reference's exported decoder shape (whisper_to_cml.py:28)
     got1 = ctx.decode_logits(toks[:, :1], xa)
     assert np.array_equal(got1[:, 0], got[:, 0])
@@ -292,13 +326,13 @@ def test_tiny_en_dimensions(pkg):
     want = R.encode(sd, dims, mel).numpy()
     e = R.rel_l2(got, want)
     print("tiny.en encoder rel-L2", e)
-    assert e <= ENC_TOL
+    assert gate("tiny_en.enc", e)
     toks = np.array([[50257, 50362, 100, 2000]], np.int32)
     lg = ctx.decode_logits(toks, want)
     ref = R.decode_logits(sd, dims, toks, want).numpy()
     e2 = R.rel_l2(lg, ref)
     print("tiny.en logits rel-L2", e2)
-    assert e2 <= LOGIT_TOL
+    assert gate("tiny_en.logits", e2)
     # BASELINE.json configs[1] as written: greedy decode of a single chunk (the flat cross-attention launch + combine,
     # 6 heads x 1 sequence), every choice against the oracle teacher-forced on the GPU's prefix
     prompt = [50257, 50362]
@@ -381,14 +415,14 @@ def test_base_geometry_batch32(pkg):
     assert np.array_equal(xa[0], xa[4]) and np.array_equal(xa[1], xa[29])      # equal chunks -> equal rows
     sd = R.to_torch({n: ctx.get_tensor(n, s) for n, s, _ in W.tensor_specs(dims)})
     want = R.encode(sd, dims, mel[:2]).numpy()
-    assert R.rel_l2(xa[:2], want) <= ENC_TOL
+    assert gate("base.enc", R.rel_l2(xa[:2], want))
     prompt = [50258, 50259, 50359, 50363]
     toks, lens = ctx.transcribe_greedy(pcm, prompt, 4)
     assert toks.shape == (32, 4) and np.array_equal(toks[0], toks[4]) and np.array_equal(toks[17], toks[21])
     # the greedy choices of the B = 32 run against the oracle: rows from both batch blocks of the decode groups
     rows = [0, 1, 2, 3, 17, 30]
     want6 = R.encode(sd, dims, mel[rows]).numpy()
-    assert R.rel_l2(xa[rows], want6) <= ENC_TOL
+    assert gate("base.enc_rows", R.rel_l2(xa[rows], want6))
     _check_greedy_against_teacher_forced_oracle(sd, dims, want6, prompt, toks[rows])
     ctx.close()
 
@@ -408,7 +442,7 @@ def test_large_v3_front_end_and_vocabulary(pkg):
     want = R.encode(sd, dims, mel).numpy()
     e = R.rel_l2(xa, want)
     print("large-v3 (2 layers) encoder rel-L2", e)
-    assert e <= ENC_TOL
+    assert gate("large_v3_2layer.enc", e)
     got = ctx.detect_language(want, sot=50258, lang_first=50259, lang_last=50358)
     _, conf = R.detect_language(sd, dims, want, sot=50258, lang_first=50259, lang_last=50358)
     assert conf.shape == (2, 100)
@@ -422,7 +456,7 @@ def test_large_v3_front_end_and_vocabulary(pkg):
     ref_l = R.decode_logits(sd, dims, tok, want).numpy()
     e = R.rel_l2(got_l, ref_l)
     print("large-v3 (2 layers) logits rel-L2", e)
-    assert e <= LOGIT_TOL
+    assert gate("large_v3_2layer.logits", e)
     # ... and a decode group of 20 sequences (two batch blocks at this width) equals the same chunks alone
     idx = [0, 1] * 10
     many, _ = ctx.transcribe_greedy(pcm[idx], [50258, 50259, 50360, 50364], 3)
@@ -683,7 +717,7 @@ def test_full_depth_large_v2_against_the_oracle(pkg):
     ref = R.decode_logits(sd, dims, tok, want).numpy()
     e_log = R.rel_l2(got, ref)
     print("large-v2 full depth: encoder rel-L2 %.3e, logits rel-L2 %.3e" % (e_enc, e_log))
-    assert e_enc <= ENC_TOL and e_log <= LOGIT_TOL
+    assert gate("large_v2_full.enc", e_enc) and gate("large_v2_full.logits", e_log)
     for t in range(4):
         _check_choice(ref[0, t], int(got[0, t].argmax()))
     ctx.close()
@@ -717,7 +751,7 @@ def test_full_text_context_and_degenerate_audio(lively):
     xa0 = ctx.encode_mel(mel0)
     assert np.isfinite(xa0).all()
     want0 = R.encode(sd, dims, mel0).numpy()
-    assert R.rel_l2(xa0, want0) <= ENC_TOL
+    assert gate("tiny_lively.enc_silence", R.rel_l2(xa0, want0))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -771,12 +805,12 @@ def test_small_geometry_the_reference_model(pkg):
     xa = ctx.encode_mel(mel)
     want = R.encode(sd, dims, mel).numpy()
     e_enc = R.rel_l2(xa, want)
-    assert xa.shape == (2, 1500, 768) and e_enc <= ENC_TOL, e_enc
+    assert xa.shape == (2, 1500, 768) and gate("small_full.enc", e_enc)
     sot = np.full((2, 1), 50258, np.int32)                                  # Whisper.swift:34-35
     got = ctx.decode_logits(sot, want)
     ref = R.decode_logits(sd, dims, sot, want).numpy()
     e_log = R.rel_l2(got, ref)
-    assert got.shape == (2, 1, 51865) and e_log <= LOGIT_TOL, e_log
+    assert got.shape == (2, 1, 51865) and gate("small_full.logits_t1", e_log)
     lang = ctx.detect_language(want)                                        # :37-38, ids 50259...50357
     _, conf = R.detect_language(sd, dims, want)
     for b in range(2):
@@ -807,7 +841,7 @@ def test_large_v2_batch8_greedy_choices_against_the_oracle(pkg):
     assert toks.shape == (8, 16) and np.all(lens == 16)
     want = R.encode(sd, dims, mel).numpy()
     e_enc = R.rel_l2(ctx.encode_mel(mel), want)
-    assert e_enc <= ENC_TOL, e_enc
+    assert gate("large_v2_full_b8.enc", e_enc)
     worst = _check_greedy_against_teacher_forced_oracle(sd, dims, want, prompt, toks)
     print("large-v2 full depth, B = 8 x 16 tokens: encoder rel-L2 %.3e, worst greedy gap %.3g logit" % (e_enc, worst))
     ctx.close()
@@ -834,7 +868,7 @@ def test_large_v3_full_depth_one_chunk(pkg):
     ref = R.decode_logits(sd, dims, tok, want).numpy()
     e_log = R.rel_l2(got, ref)
     print("large-v3 full depth: encoder rel-L2 %.3e, logits rel-L2 %.3e" % (e_enc, e_log))
-    assert got.shape == (1, 4, 51866) and e_enc <= ENC_TOL and e_log <= LOGIT_TOL
+    assert got.shape == (1, 4, 51866) and gate("large_v3_full.enc", e_enc) and gate("large_v3_full.logits", e_log)
     lang = ctx.detect_language(want, sot=50258, lang_first=50259, lang_last=50358)
     _, conf = R.detect_language(sd, dims, want, sot=50258, lang_first=50259, lang_last=50358)
     _check_choice(conf[0], int(lang[0]))
@@ -1012,10 +1046,10 @@ def test_converted_checkpoints_load_and_match_the_oracle(pkg, tmp_path):
         _, mel = mels(ctx, 1)
         xa = ctx.encode_mel(mel)
         want = R.encode(sd, dims, mel).numpy()
-        assert R.rel_l2(xa, want) <= ENC_TOL
+        assert gate("converted.enc", R.rel_l2(xa, want))
         tok = np.array([[10, 21, 5, 7]], np.int32)
         lg = ctx.decode_logits(tok, want)
-        assert R.rel_l2(lg, R.decode_logits(sd, dims, tok, want).numpy()) <= LOGIT_TOL
+        assert gate("converted.logits", R.rel_l2(lg, R.decode_logits(sd, dims, tok, want).numpy()))
         outs.append((xa, lg))
         ctx.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])   # same weights either way
@@ -1044,7 +1078,7 @@ def test_layernorm_fold_is_robust_to_a_common_mode_offset(pkg):
         tok = np.array([[10, 21, 5, 7, 100, 200]], np.int32)
         e = R.rel_l2(ctx.decode_logits(tok, xa), R.decode_logits(sd, dims, tok, xa).numpy())
         errs.append(e)
-        assert e <= LOGIT_TOL, (off, outl, e)
+        assert gate("offset_%g_%g.logits" % (off, outl), e, TOL["offset.logits"])
         toks, _ = ctx.transcribe_greedy(np.stack([L.synth_chunk(3)]), [10, 21, 5, 7], 6)     # the graph-replayed path too
         _check_greedy_against_teacher_forced_oracle(sd, dims, xa, [10, 21, 5, 7], toks)
         ctx.close()
@@ -1155,7 +1189,7 @@ def test_decode_policy_at_the_production_vocabulary(pkg, model, TS):
         # the values first: teacher-forced logits of the GPU vs the oracle on this model (the stated relative tolerance)
         seq0 = np.concatenate([prompt, got[0]])[None, :8].astype(np.int32)
         e_log = R.rel_l2(ctx.decode_logits(seq0, xa[:1]), R.decode_logits(sd, dims, seq0, xa[:1]).numpy())
-        assert e_log <= LOGIT_TOL, e_log
+        assert gate("%s_policy.logits" % model, e_log, TOL["policy.logits"])
         n_forced, n_near = _check_policy_choices(sd, dims, xa, prompt, got, suppress, [220, EOT], TS, EOT, MAXI)
         n_text = int((got < TS).sum())
         print("%s production vocabulary: %d text / %d timestamp tokens, %d forced by the sum rule, %d near-ties, "
@@ -1385,5 +1419,48 @@ def test_timed_workload_against_the_oracle_at_its_own_size(pkg):
     print("large-v2 full depth, lively, 56-row group x 224 tokens: worst greedy gap %.3g logit (rms %.2f); teacher-forced "
           "logits rel-L2 %.3e over 227 positions, %.3e over the last 32; arg-max agreement %.3f"
           % (worst, float(np.sqrt((ref.astype(np.float64) ** 2).mean())), e_all, e_tail, agree))
-    assert e_all <= LOGIT_TOL and e_tail <= LOGIT_TOL, (e_all, e_tail)
+    assert gate("workload.logits_all", e_all) and gate("workload.logits_tail", e_tail)
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", ["tiny", "tiny_lively", "tiny.en", "small_2layer", "large-v2_full"])
+def test_fp32_debug_path_matches_the_oracle(pkg, case):
+    """BASELINE.md's parity gate: "fp32 debug path must match to <= 1e-4 rel-L2" (VERDICT r3 next #2).  The debug library's
+    wmdbg_set_precision(ctx, WM_F32) runs wm_encode / wm_decode_logits with f32 activations, f32 K/V and f32 accumulation on
+    the product's own weight buffers (bf16 values, product layouts: csrc/f32_path.hip).  Encoder output AND teacher-forced
+    logits within 1e-4 of oracle/whisper_ref.py (measured 1e-7 .. 3e-6, profiles/r04_parity_margins.txt) at tiny dims, tiny.en
+    in full, small (2 + 2 layers) and large-v2 at FULL depth -- so whatever the bf16 product path differs by at the same
+    geometry (3e-4 .. 5e-3 encoder, 4e-3 .. 6e-3 logits) is rounding, not semantics, layout or indexing.  The same context
+    switched back to WM_BF16 must reproduce the product library's own output bit for bit."""
+    import torch
+    MD = pkg.binding.MODEL_DIMS
+    dims, seed, gain, toks = {
+        "tiny": (dict(R.TINY_DIMS), 11, 1.0, [1, 7, 300, 1023, 5, 9]),
+        "tiny_lively": (dict(R.TINY_DIMS), 11, LIVELY_GAIN, [1, 7, 300, 1023, 5, 9]),
+        "tiny.en": (MD["tiny.en"], 7, 1.0, [50257, 50362, 100, 2000]),
+        "small_2layer": (dict(MD["small"], n_audio_layer=2, n_text_layer=2), 19, 1.0, [50258, 50259, 50359, 50363, 1000]),
+        "large-v2_full": (MD["large-v2"], 7, 1.0, [50258, 50259, 50359, 50363, 1000]),
+    }[case]
+    ctx = pkg.binding.Context(dims, debug=True)
+    ctx.init_synthetic(seed, matrix_gain=gain)
+    _perturb_ln_on_device(ctx, dims)
+    ctx.finalize()
+    sd = _oracle_weights(ctx, dims)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    n = 1 if case == "large-v2_full" else 2
+    pcm = np.stack([tone_chunk(1), L.synth_chunk(5)][:n])
+    mel = ctx.logmel(pcm, out_dtype=np.float32)
+    want = R.encode(sd, dims, mel).numpy()
+    tok = np.tile(np.asarray(toks, np.int32), (n, 1))
+    ref = R.decode_logits(sd, dims, tok, want).numpy()
+    bf_xa, bf_lg = ctx.encode_mel(mel), ctx.decode_logits(tok, want)
+    ctx.set_precision(True)
+    xa, lg = ctx.encode_mel(mel), ctx.decode_logits(tok, want)
+    e_enc, e_log = R.rel_l2(xa, want), R.rel_l2(lg, ref)
+    print("%s: fp32 debug path encoder rel-L2 %.2e, logits %.2e (bf16 product path: %.2e, %.2e)"
+          % (case, e_enc, e_log, R.rel_l2(bf_xa, want), R.rel_l2(bf_lg, ref)))
+    assert gate("f32.enc", e_enc) and gate("f32.logits", e_log)
+    assert np.array_equal(lg.argmax(-1), ref.argmax(-1))
+    ctx.set_precision(False)
+    assert np.array_equal(ctx.encode_mel(mel), bf_xa) and np.array_equal(ctx.decode_logits(tok, want), bf_lg)
     ctx.close()
