@@ -4,8 +4,9 @@ against the fp32 PyTorch oracle (oracle/whisper_ref.py) on identical synthetic w
 Tolerances (stated here, as BASELINE.md asks): the HIP path computes GEMM inputs, K/V caches
 and attention probabilities in bf16 with fp32 accumulation, fp32 LayerNorm / softmax /
 residual stream.  Against the all-fp32 oracle that gives
-    encoder output (post ln_post)  rel-L2 <= 5e-3   (measured 3e-4 .. 1.1e-3)
-    teacher-forced logits          rel-L2 <= 1e-2   (measured 3e-3 .. 4e-3)
+    encoder output (post ln_post)  rel-L2 <= 5e-3   (measured 2.8e-4 at two layers .. 3.4e-3 at 32; per-site gates in TOL)
+    teacher-forced logits          rel-L2 <= 1e-2   (measured 2.1e-3 .. 6.9e-3; per-site gates in TOL)
+and the ALL-FP32 debug path (debug library, wmdbg_set_precision) <= 1e-4 as BASELINE.md requires (measured <= 2.2e-6)
 and arg-max decisions are checked by margin: the token the GPU picks must be within
 0.05 logit units of the oracle's maximum (exact equality whenever the oracle's top-2 gap is
 larger than that)."""
@@ -24,18 +25,37 @@ W = importlib.import_module("openai_whisper_coreml_amd.weights")
 ENC_TOL = 5e-3
 LOGIT_TOL = 1e-2
 MARGIN = 0.05
-# Per-site gates (rel-L2 against the fp32 oracle).  Every value is <= 3x what the site measured on an MI355X
+# Per-site gates (rel-L2 against the fp32 oracle).  Every gate is <= 3x what the site measured on an MI355X
 # (profiles/r04_parity_margins_tests.txt, written by this module's own run: gate() records every measurement); ENC_TOL /
-# LOGIT_TOL above are the envelope BASELINE.md states, no site is looser than 3x its own measurement.
-TOL = {
-    "tiny.enc": ENC_TOL, "tiny.logits": LOGIT_TOL, "golden.enc_rows": ENC_TOL, "golden.logits_head": 2 * LOGIT_TOL,
-    "tiny_en.enc": ENC_TOL, "tiny_en.logits": LOGIT_TOL, "base.enc": ENC_TOL, "base.enc_rows": ENC_TOL,
-    "large_v3_2layer.enc": ENC_TOL, "large_v3_2layer.logits": LOGIT_TOL, "large_v2_full.enc": ENC_TOL,
-    "large_v2_full.logits": LOGIT_TOL, "tiny_lively.enc_silence": ENC_TOL, "small_full.enc": ENC_TOL,
-    "small_full.logits_t1": LOGIT_TOL, "large_v2_full_b8.enc": ENC_TOL, "large_v3_full.enc": ENC_TOL,
-    "large_v3_full.logits": LOGIT_TOL, "converted.enc": ENC_TOL, "converted.logits": LOGIT_TOL, "offset.logits": LOGIT_TOL,
-    "policy.logits": LOGIT_TOL, "workload.logits_all": LOGIT_TOL, "workload.logits_tail": LOGIT_TOL,
-    "f32.enc": 1e-4, "f32.logits": 1e-4,
+# LOGIT_TOL above are the envelope (the worst sites: 32-layer encoders 3.4e-3, lively full-depth logits 6.9e-3).
+TOL = {   # name: gate                 measured on MI355X (round 4)   gate / measured
+    "tiny.enc": 8e-4,               # 2.85e-04   2.8x
+    "golden.enc_rows": 1e-3,        # 3.45e-04   2.9x
+    "golden.logits_head": 1e-2,     # 3.34e-03   3.0x
+    "tiny.logits": 1e-2,            # 4.38e-03   2.3x
+    "tiny_en.enc": 3.3e-3,          # 1.14e-03   2.9x
+    "tiny_en.logits": 1e-2,         # 3.88e-03   2.6x
+    "base.enc": 5e-3,               # 1.75e-03   2.9x
+    "base.enc_rows": 5e-3,          # 1.75e-03   2.9x
+    "large_v3_2layer.enc": 5e-3,    # 2.12e-03   2.4x
+    "large_v3_2layer.logits": 1e-2,  # 3.61e-03   2.8x
+    "large_v2_full.enc": 5e-3,      # 3.31e-03   1.5x
+    "large_v2_full.logits": 1e-2,   # 4.01e-03   2.5x
+    "tiny_lively.enc_silence": 5e-3,  # 2.81e-03   1.8x
+    "small_full.enc": 5e-3,         # 2.66e-03   1.9x
+    "small_full.logits_t1": 1e-2,   # 5.10e-03   2.0x
+    "large_v2_full_b8.enc": 5e-3,   # 3.33e-03   1.5x
+    "large_v3_full.enc": 5e-3,      # 3.36e-03   1.5x
+    "large_v3_full.logits": 1e-2,   # 5.06e-03   2.0x
+    "converted.enc": 8e-4,          # 2.82e-04   2.8x
+    "converted.logits": 1e-2,       # 4.21e-03   2.4x
+    "offset.logits": 1e-2,          # 4.35e-03 .. 4.68e-03 (offsets 0 / 3 / 10)   2.1x
+    "offset_outlier.logits": 6e-3,  # 2.07e-03 (offset 3 + a massive-activation feature)   2.9x
+    "policy.logits": 1e-2,          # 6.87e-03 / 6.49e-03 (lively, production vocabulary)   1.5x
+    "workload.logits_all": 1e-2,    # 6.83e-03 (lively large-v2, full depth, 227 positions)   1.5x
+    "workload.logits_tail": 1e-2,   # 6.79e-03   1.5x
+    # the all-fp32 debug path: BASELINE.md's gate is 1e-4; measured 1.3e-07 .. 2.2e-06 (large-v2 full depth)
+    "f32.enc": 7e-6, "f32.logits": 7e-6,
 }
 _MEASURED = []
 
@@ -1078,7 +1098,7 @@ def test_layernorm_fold_is_robust_to_a_common_mode_offset(pkg):
         tok = np.array([[10, 21, 5, 7, 100, 200]], np.int32)
         e = R.rel_l2(ctx.decode_logits(tok, xa), R.decode_logits(sd, dims, tok, xa).numpy())
         errs.append(e)
-        assert gate("offset_%g_%g.logits" % (off, outl), e, TOL["offset.logits"])
+        assert gate("offset_%g_%g.logits" % (off, outl), e, TOL["offset_outlier.logits" if outl else "offset.logits"])
         toks, _ = ctx.transcribe_greedy(np.stack([L.synth_chunk(3)]), [10, 21, 5, 7], 6)     # the graph-replayed path too
         _check_greedy_against_teacher_forced_oracle(sd, dims, xa, [10, 21, 5, 7], toks)
         ctx.close()
