@@ -57,6 +57,8 @@ struct DecGemvDev {
     const float *c1;        // LayerNorm fold: c1[n] = sum_k W'_nk (the folded, rounded weights); plain modes: unused
     const float *c2;        // bias[n] (+ sum_k beta_k W_nk in LayerNorm modes); may be null
     const bf16_t *a;        // [B][K] bf16 activations: bf16 copy of the residual, attention output or GELU output
+    const float *att_part;  // MERGE kernels: the cross-attention's stream partials [B][att_heads][8][66] (m, l, o[64]) -- the
+    int att_heads;          //   A operand is the merged head output, formed on load (no combine launch; see dec_gemv_kernel)
     const float *stats_in;  // LayerNorm: [blk][stats_parts][16][2] partial (sum x, sum x^2) per row of the f32 residual
     int stats_parts;
     long stats_stride;      // floats between the statistics of consecutive 16-row batch blocks
@@ -106,6 +108,24 @@ __device__ __forceinline__ void l2_warm_tile(const char *base, long tile_bytes, 
 #pragma unroll
         for (int u = 0; u < 8; ++u) asm volatile("" ::"v"(v[u]));
     }
+}
+
+// merged head-output element of a (sequence, head) pair from its NS stream partials (m, l, o): the ONE place the merge
+// arithmetic is written -- the attention kernel's own tail, the combine launch and the out-projection GEMV that merges on
+// load all call it, so the three launch shapes give the same bits
+template <int NS>
+__device__ __forceinline__ float attn_merge_core(const float (&m)[NS], const float (&l)[NS], const float (&o)[NS]) {
+    float M = m[0];
+#pragma unroll
+    for (int w = 1; w < NS; ++w) M = fmaxf(M, m[w]);
+    float acc = 0.f, L = 0.f;
+#pragma unroll
+    for (int w = 0; w < NS; ++w) {
+        const float f = __expf(m[w] - M);  // a stream that saw no row has m = -1e30, l = 0, o = 0
+        acc = __fmaf_rn(o[w], f, acc);
+        L = __fmaf_rn(l[w], f, L);
+    }
+    return acc / L;
 }
 
 // The decode GEMV (round 2): out[b][n] = sum_k a[b][k] W[n][k] for a decode group of any size.
@@ -314,8 +334,12 @@ __device__ __forceinline__ void gemv_unit_epilogue(const DecGemvDev &p, const Ge
 // than one batch block its (tile, block) grid then fits one residency round of the chip instead of two (one extra L2
 // round trip inside the workgroup, a whole kernel time saved).  The parts, their MFMA chains and the order they are
 // added in are the same: bit-identical results.
-template <int SPW, int TN, int NBLK, int EPI, bool LN, int PPW = 1>
-__global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512 : 1024) void dec_gemv_kernel(DecGemvDev p) {
+// MERGE (the out-projection behind a SPLIT cross-attention, i.e. fewer than 96 (sequence, head) pairs): the A operand is
+// not read as bf16 head outputs but formed on load from the attention's 8 stream partials per pair with attn_merge_core
+// -- the arithmetic of the combine launch, so the bits are those of the other launch shapes -- which removes that launch
+// from every decoder layer of a small decode group (tiny.en, single chunk: 38 -> 34 launches per position).
+template <int SPW, int TN, int NBLK, int EPI, bool LN, int PPW = 1, bool MERGE = false>
+__global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1 || MERGE) ? 512 : 1024) void dec_gemv_kernel(DecGemvDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NU = TN * NBLK;
     const int NW = blockDim.x >> 6;
@@ -371,6 +395,43 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
         for (int j = 0; j < NBLK; ++j) {
             const int blk = (bb >> 4) + j;
             const int blkc = blk * 16 < p.B ? blk : (bb >> 4);  // a missing second block re-reads the first (never used)
+            if (MERGE) {
+                // fragment element (row b = blk * 16 + lane % 16, k = step * 32 + (lane / 16) * 8 + i): head k / 64, e = k % 64
+                int b = blkc * 16 + (lane & 15);
+                b = b < p.B ? b : p.B - 1;   // rows past B: a valid row's partials (their products are never stored)
+#pragma unroll
+                for (int u = 0; u < SPW; ++u) {
+                    const int k0 = (part * SPW + u) * 32 + (lane >> 4) * 8;
+                    const float *pp = p.att_part + ((long)(b * p.att_heads + (k0 >> 6)) * 8) * 66;
+                    float2 ml[8];
+                    float2 ov[8][4];
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {
+                        ml[w] = *(const float2 *)(pp + w * 66);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) ov[w][i] = *(const float2 *)(pp + w * 66 + 2 + (k0 & 63) + 2 * i);
+                    }
+                    float mm[8], ll[8];
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {
+                        mm[w] = ml[w].x;
+                        ll[w] = ml[w].y;
+                    }
+                    unsigned pk[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float o0[8], o1[8];
+#pragma unroll
+                        for (int w = 0; w < 8; ++w) {
+                            o0[w] = ov[w][i].x;
+                            o1[w] = ov[w][i].y;
+                        }
+                        pk[i] = (unsigned)f2bf(attn_merge_core<8>(mm, ll, o0)) | ((unsigned)f2bf(attn_merge_core<8>(mm, ll, o1)) << 16);
+                    }
+                    af[j][u] = (u32x4){pk[0], pk[1], pk[2], pk[3]};
+                }
+                continue;
+            }
             const bf16_t *ap = p.a + (((long)blkc * (p.K >> 5) + (long)part * SPW) * 64 + lane) * 8;
 #pragma unroll
             for (int u = 0; u < SPW; ++u) af[j][u] = *(const u32x4 *)(ap + u * 512);
@@ -543,20 +604,17 @@ constexpr int ATT_MAXK = 1536;
 #define WM_XATTN_NT true  // cross-attention K/V rows: non-temporal loads (A/B builds: -DWM_XATTN_NT=false)
 #endif
 
-// merged head-output element e of a pair from its NS stream partials (m, l, o): the one place the merge is written
+// merged head-output element e of a pair from NS stream partials held in arrays (LDS / HBM): see attn_merge_core
 template <int NS>
 __device__ __forceinline__ float attn_merge(const float *m, const float *l, const float *o, int ostride, int e) {
-    float M = m[0];
-#pragma unroll
-    for (int w = 1; w < NS; ++w) M = fmaxf(M, m[w]);
-    float acc = 0.f, L = 0.f;
+    float mm[NS], ll[NS], oo[NS];
 #pragma unroll
     for (int w = 0; w < NS; ++w) {
-        const float f = __expf(m[w] - M);  // a stream that saw no row has m = -1e30, l = 0, o = 0
-        acc = __fmaf_rn(o[w * ostride + e], f, acc);
-        L = __fmaf_rn(l[w], f, L);
+        mm[w] = m[w];
+        ll[w] = l[w];
+        oo[w] = o[w * ostride + e];
     }
-    return acc / L;
+    return attn_merge_core<NS>(mm, ll, oo);
 }
 
 template <int NS, int U, bool NT>
@@ -965,6 +1023,15 @@ int launch_gemv_shape(wm_ctx *ctx, const DecGemvDev &p, int tn, int nblk, int nw
     }
     const size_t lds = (size_t)nw * tn * nblk * 1024 + (size_t)nw * 32 * 4;
     const int th = nw * 64;
+    if (p.att_part) {   // merge-on-load out-projection (one batch block, one tile per workgroup: small decode groups only)
+        // two k-steps per wave only (K = d <= 512: tiny / base): a step needs 80 floats of partials per lane, and with
+        // more steps in flight the kernel spills (SPW 4: 85 registers, SPW 5: 187) -- wider models keep the combine launch
+        constexpr bool CAN = !LN && EPI == DE_RESID && SPW == 2;
+        if (!CAN || tn != 1 || nblk != 1 || ppw != 1) { wm_set_error("dec_gemv: no merging kernel for this shape"); return WM_ERR_INVALID; }
+        dec_gemv_kernel<CAN ? SPW : 2, 1, 1, CAN ? EPI : DE_RESID, CAN ? LN : false, 1, true><<<grid, th, lds, s>>>(p);
+        WM_HIP(hipGetLastError());
+        return WM_OK;
+    }
     constexpr bool WIDE = LN && (EPI == DE_QKV || EPI == DE_GELU || EPI == DE_LOGITS) && SPW <= 6;
     if (tn == 1 && nblk == 1) dec_gemv_kernel<SPW, 1, 1, EPI, LN><<<grid, th, lds, s>>>(p);
     else if (tn == 1 && nblk == 2 && SPW <= 8) dec_gemv_kernel<SPW <= 8 ? SPW : 2, 1, 2, EPI, LN><<<grid, th, lds, s>>>(p);
@@ -1057,11 +1124,14 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     const bool ln = a.c1 != nullptr;
     WM_REQUIRE(!ln || (a.stats_in && a.K % 64 == 0 && a.K / 16 <= 80), WM_ERR_INVALID,
                "dec_gemv: LayerNorm mode needs the producer's K/16 partial statistics (K a multiple of 64, <= 1280)");
-    WM_REQUIRE(a.a != nullptr && a.W != nullptr, WM_ERR_INVALID, "dec_gemv: null operand");
+    WM_REQUIRE((a.a != nullptr || a.att_part != nullptr) && a.W != nullptr, WM_ERR_INVALID, "dec_gemv: null operand");
     DecGemvDev p;
     memset(&p, 0, sizeof(p));
     p.B = a.B; p.N = a.N; p.K = a.K;
     p.W = a.W; p.c1 = a.c1; p.c2 = a.c2; p.a = a.a;
+    p.att_part = a.att_part; p.att_heads = a.att_heads;
+    WM_REQUIRE(!a.att_part || (a.epi == DE_RESID && !ln && a.B <= 16 && a.K == a.att_heads * 64), WM_ERR_INVALID,
+               "dec_gemv: merge-on-load is the out-projection of a split cross-attention (<= 16 rows, K = heads x 64)");
     p.stats_in = a.stats_in; p.stats_parts = a.K / 16; p.stats_out = a.stats_out;
     p.mean_in = a.mean_in; p.mean_out = a.mean_out;
     p.stats_stride = 2L * (a.epi == DE_RESID ? a.N : a.K);  // [parts <= d/16][16][2] floats per block of 16 rows
@@ -1152,7 +1222,8 @@ int wm_dec_attn_splits(int B, int H) {
 
 int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
                      int T_stride, int n_keys, const int *pos_ptr, int nsplit, float *part, bf16_t *att,
-                     bool cross, const bf16_t *pf_ptr, int pf_rows, int pf_k, const int *live_rows, const int *n_live) {
+                     bool cross, const bf16_t *pf_ptr, int pf_rows, int pf_k, const int *live_rows, const int *n_live,
+                     bool combine) {
     WM_REQUIRE(nsplit == 1 || nsplit == 2 || nsplit == 4 || nsplit == 8, WM_ERR_INVALID,
                "dec_attention: nsplit %d is not 1, 2, 4 or 8", nsplit);
     WM_REQUIRE(T_stride <= ATT_MAXK && n_keys <= ATT_MAXK, WM_ERR_INVALID,
@@ -1207,7 +1278,7 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
         }
         WM_HIP(hipGetLastError());
     }
-    if (nsplit > 1) {
+    if (nsplit > 1 && combine) {   // (combine == false: the consumer merges the partials itself, DecGemvArgs::att_part)
         WmProfScope ps(&ctx->prof, "dec_attn_combine", ctx->stream);
         dec_attn_combine_kernel<8><<<B * H, 64, 0, ctx->stream>>>(part, H, H * 64, att);
         WM_HIP(hipGetLastError());

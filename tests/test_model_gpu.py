@@ -1484,3 +1484,44 @@ def test_fp32_debug_path_matches_the_oracle(pkg, case):
     ctx.set_precision(False)
     assert np.array_equal(ctx.encode_mel(mel), bf_xa) and np.array_equal(ctx.decode_logits(tok, want), bf_lg)
     ctx.close()
+
+
+def test_merge_on_load_out_projection_equals_the_combine_launch(pkg):
+    """Round 4 (the tiny.en half): below 96 (sequence, head) pairs the cross-attention runs as a flat
+    deal of (pair, stream) units and used to be followed by a combine launch; at d <= 512 the out-projection GEMV now merges
+    the 8 stream partials of a pair ON LOAD with the same function (attn_merge_core), so a decoder layer of a small decode
+    group is 8 launches again.  Same bits three ways at tiny.en: (a) merge-on-load vs the combine launch (debug tuning, a
+    second context so that no captured graph is reused), (b) a row decoded alone (6 pairs: flat + merge-on-load) vs the
+    same row inside a batch of 16 (96 pairs: one workgroup per pair, in-kernel merge), logits and greedy tokens."""
+    import ctypes
+    dims = pkg.binding.MODEL_DIMS["tiny.en"]
+    pcm = tones(3)
+    prompt = [50257, 50362]
+    rng = np.random.default_rng(3)
+    tok = rng.integers(0, 51864, size=(16, 5)).astype(np.int32)
+    outs = []
+    lib = pkg.binding.load_debug_library()
+    lib.wmdbg_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    try:
+        for no_merge in (0, 1):
+            assert lib.wmdbg_set_tuning(b"no_merge_on_load", no_merge) == 0
+            ctx = pkg.binding.Context(dims, debug=True)
+            ctx.init_synthetic(17, matrix_gain=LIVELY_GAIN)
+            _perturb_ln_on_device(ctx, dims, seed=5)
+            ctx.finalize()
+            xa = ctx.encode_mel(ctx.logmel(pcm, out_dtype=np.float32))
+            xa16 = xa[[i % 3 for i in range(16)]]
+            lg1 = ctx.decode_logits(tok[:1], xa16[:1])            # 6 pairs: flat cross-attention
+            lg3 = ctx.decode_logits(tok[:3], xa16[:3])            # 18 pairs
+            lg16 = ctx.decode_logits(tok, xa16)                   # 96 pairs: one workgroup per pair, merged in the kernel
+            gen, _ = ctx.transcribe_greedy(pcm, prompt, 40)
+            solo, _ = ctx.transcribe_greedy(pcm[1:2], prompt, 40)
+            outs.append((lg1, lg3, lg16, gen, solo))
+            ctx.close()
+    finally:
+        lib.wmdbg_set_tuning(b"reset", 0)
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)                               # (a) merge-on-load == combine launch
+    lg1, lg3, lg16, gen, solo = outs[0]
+    assert np.array_equal(lg1[0], lg16[0]) and np.array_equal(lg3, lg16[:3])   # (b) across launch shapes
+    assert np.array_equal(solo[0], gen[1]) and len({r.tobytes() for r in gen}) == 3
