@@ -57,8 +57,6 @@ struct DecGemvDev {
     const float *c1;        // LayerNorm fold: c1[n] = sum_k W'_nk (the folded, rounded weights); plain modes: unused
     const float *c2;        // bias[n] (+ sum_k beta_k W_nk in LayerNorm modes); may be null
     const bf16_t *a;        // [B][K] bf16 activations: bf16 copy of the residual, attention output or GELU output
-    const float *att_part;  // MERGE kernels: the cross-attention's stream partials [B][att_heads][8][66] (m, l, o[64]) -- the
-    int att_heads;          //   A operand is the merged head output, formed on load (no combine launch; see dec_gemv_kernel)
     const float *stats_in;  // LayerNorm: [blk][stats_parts][16][2] partial (sum x, sum x^2) per row of the f32 residual
     int stats_parts;
     long stats_stride;      // floats between the statistics of consecutive 16-row batch blocks
@@ -111,8 +109,8 @@ __device__ __forceinline__ void l2_warm_tile(const char *base, long tile_bytes, 
 }
 
 // merged head-output element of a (sequence, head) pair from its NS stream partials (m, l, o): the ONE place the merge
-// arithmetic is written -- the attention kernel's own tail, the combine launch and the out-projection GEMV that merges on
-// load all call it, so the three launch shapes give the same bits
+// arithmetic is written -- the attention kernel's own tail and the combine launch both call it, so the launch shapes give
+// the same bits
 template <int NS>
 __device__ __forceinline__ float attn_merge_core(const float (&m)[NS], const float (&l)[NS], const float (&o)[NS]) {
     float M = m[0];
@@ -334,12 +332,8 @@ __device__ __forceinline__ void gemv_unit_epilogue(const DecGemvDev &p, const Ge
 // than one batch block its (tile, block) grid then fits one residency round of the chip instead of two (one extra L2
 // round trip inside the workgroup, a whole kernel time saved).  The parts, their MFMA chains and the order they are
 // added in are the same: bit-identical results.
-// MERGE (the out-projection behind a SPLIT cross-attention, i.e. fewer than 96 (sequence, head) pairs): the A operand is
-// not read as bf16 head outputs but formed on load from the attention's 8 stream partials per pair with attn_merge_core
-// -- the arithmetic of the combine launch, so the bits are those of the other launch shapes -- which removes that launch
-// from every decoder layer of a small decode group (tiny.en, single chunk: 38 -> 34 launches per position).
-template <int SPW, int TN, int NBLK, int EPI, bool LN, int PPW = 1, bool MERGE = false>
-__global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1 || MERGE) ? 512 : 1024) void dec_gemv_kernel(DecGemvDev p) {
+template <int SPW, int TN, int NBLK, int EPI, bool LN, int PPW = 1>
+__global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512 : 1024) void dec_gemv_kernel(DecGemvDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NU = TN * NBLK;
     const int NW = blockDim.x >> 6;
@@ -395,43 +389,6 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1 || MER
         for (int j = 0; j < NBLK; ++j) {
             const int blk = (bb >> 4) + j;
             const int blkc = blk * 16 < p.B ? blk : (bb >> 4);  // a missing second block re-reads the first (never used)
-            if (MERGE) {
-                // fragment element (row b = blk * 16 + lane % 16, k = step * 32 + (lane / 16) * 8 + i): head k / 64, e = k % 64
-                int b = blkc * 16 + (lane & 15);
-                b = b < p.B ? b : p.B - 1;   // rows past B: a valid row's partials (their products are never stored)
-#pragma unroll
-                for (int u = 0; u < SPW; ++u) {
-                    const int k0 = (part * SPW + u) * 32 + (lane >> 4) * 8;
-                    const float *pp = p.att_part + ((long)(b * p.att_heads + (k0 >> 6)) * 8) * 66;
-                    float2 ml[8];
-                    float2 ov[8][4];
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) {
-                        ml[w] = *(const float2 *)(pp + w * 66);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) ov[w][i] = *(const float2 *)(pp + w * 66 + 2 + (k0 & 63) + 2 * i);
-                    }
-                    float mm[8], ll[8];
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) {
-                        mm[w] = ml[w].x;
-                        ll[w] = ml[w].y;
-                    }
-                    unsigned pk[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float o0[8], o1[8];
-#pragma unroll
-                        for (int w = 0; w < 8; ++w) {
-                            o0[w] = ov[w][i].x;
-                            o1[w] = ov[w][i].y;
-                        }
-                        pk[i] = (unsigned)f2bf(attn_merge_core<8>(mm, ll, o0)) | ((unsigned)f2bf(attn_merge_core<8>(mm, ll, o1)) << 16);
-                    }
-                    af[j][u] = (u32x4){pk[0], pk[1], pk[2], pk[3]};
-                }
-                continue;
-            }
             const bf16_t *ap = p.a + (((long)blkc * (p.K >> 5) + (long)part * SPW) * 64 + lane) * 8;
 #pragma unroll
             for (int u = 0; u < SPW; ++u) af[j][u] = *(const u32x4 *)(ap + u * 512);
@@ -617,8 +574,8 @@ __device__ __forceinline__ float attn_merge(const float *m, const float *l, cons
     return attn_merge_core<NS>(mm, ll, oo);
 }
 
-template <int NS, int U, bool NT>
-__global__ __launch_bounds__(NS * 64) void dec_rows_attn_kernel(const float *__restrict__ q,
+template <int NS, int U, bool NT, bool DEEP = false>
+__global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_rows_attn_kernel(const float *__restrict__ q,
                                                                 const bf16_t *__restrict__ kc,
                                                                 const bf16_t *__restrict__ vc, int H, int d,
                                                                 int T_stride, int n_keys_const,
@@ -671,8 +628,7 @@ __global__ __launch_bounds__(NS * 64) void dec_rows_attn_kernel(const float *__r
         }
         float m_run = -1e30f, l_run = 0.f;
         float oa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int r0 = 0; r0 < n_keys; r0 += NS * 8 * U) {  // workgroup-uniform trip count
-            u32x4 kv[U], vv[U];
+        auto load_block = [&](int r0, u32x4 (&kv)[U], u32x4 (&vv)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 int i = r0 + u * (NS * 8) + stream * 8 + rg;
@@ -685,6 +641,9 @@ __global__ __launch_bounds__(NS * 64) void dec_rows_attn_kernel(const float *__r
                     vv[u] = *(const u32x4 *)(vb + (long)i * 64);
                 }
             }
+        };
+        // one block of U x 8 rows of this stream: scores, block maximum, rescale, accumulate -- the stream's arithmetic
+        auto process_block = [&](int r0, const u32x4 (&kv)[U], const u32x4 (&vv)[U]) {
             float sc[U];
             float mb = -1e30f;
 #pragma unroll
@@ -721,6 +680,24 @@ __global__ __launch_bounds__(NS * 64) void dec_rows_attn_kernel(const float *__r
                 }
             }
             m_run = m_new;
+        };
+        if (DEEP) {
+            // LATENCY shape (a handful of pairs: tiny.en single chunk = 48 waves on the whole chip): a stream's rows are
+            // <= 6 blocks, and walking them one dependent memory round trip at a time was 9.2 us for 2.3 MB.  Request
+            // EVERY block first (48 x 16 B per lane), then run the same block arithmetic in the same order: same bits.
+            constexpr int NB = ATT_MAXK / (NS * 8 * U);
+            u32x4 kall[NB][U], vall[NB][U];
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) load_block(blk * (NS * 8 * U), kall[blk], vall[blk]);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+                if (blk * (NS * 8 * U) < n_keys) process_block(blk * (NS * 8 * U), kall[blk], vall[blk]);  // workgroup-uniform
+        } else {
+            for (int r0 = 0; r0 < n_keys; r0 += NS * 8 * U) {  // workgroup-uniform trip count
+                u32x4 kv[U], vv[U];
+                load_block(r0, kv, vv);
+                process_block(r0, kv, vv);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1023,18 +1000,11 @@ int launch_gemv_shape(wm_ctx *ctx, const DecGemvDev &p, int tn, int nblk, int nw
     }
     const size_t lds = (size_t)nw * tn * nblk * 1024 + (size_t)nw * 32 * 4;
     const int th = nw * 64;
-    if (p.att_part) {   // merge-on-load out-projection (one batch block, one tile per workgroup: small decode groups only)
-        // two k-steps per wave only (K = d <= 512: tiny / base): a step needs 80 floats of partials per lane, and with
-        // more steps in flight the kernel spills (SPW 4: 85 registers, SPW 5: 187) -- wider models keep the combine launch
-        constexpr bool CAN = !LN && EPI == DE_RESID && SPW == 2;
-        if (!CAN || tn != 1 || nblk != 1 || ppw != 1) { wm_set_error("dec_gemv: no merging kernel for this shape"); return WM_ERR_INVALID; }
-        dec_gemv_kernel<CAN ? SPW : 2, 1, 1, CAN ? EPI : DE_RESID, CAN ? LN : false, 1, true><<<grid, th, lds, s>>>(p);
-        WM_HIP(hipGetLastError());
-        return WM_OK;
-    }
     constexpr bool WIDE = LN && (EPI == DE_QKV || EPI == DE_GELU || EPI == DE_LOGITS) && SPW <= 6;
     if (tn == 1 && nblk == 1) dec_gemv_kernel<SPW, 1, 1, EPI, LN><<<grid, th, lds, s>>>(p);
     else if (tn == 1 && nblk == 2 && SPW <= 8) dec_gemv_kernel<SPW <= 8 ? SPW : 2, 1, 2, EPI, LN><<<grid, th, lds, s>>>(p);
+    else if (tn == 2 && nblk == 1 && WIDE && EPI == DE_LOGITS) dec_gemv_kernel<WIDE ? SPW : 2, 2, 1, WIDE ? EPI : DE_LOGITS, LN><<<grid, th, lds, s>>>(p);
+    else if (tn == 4 && nblk == 1 && WIDE && EPI == DE_LOGITS) dec_gemv_kernel<WIDE ? SPW : 2, 4, 1, WIDE ? EPI : DE_LOGITS, LN><<<grid, th, lds, s>>>(p);
     else if (tn == 2 && nblk == 2 && WIDE) dec_gemv_kernel<WIDE ? SPW : 2, 2, 2, EPI, LN><<<grid, th, lds, s>>>(p);
     else if (tn == 4 && nblk == 2 && WIDE) dec_gemv_kernel<WIDE ? SPW : 2, 4, 2, EPI, LN><<<grid, th, lds, s>>>(p);
     else { wm_set_error("dec_gemv: unsupported launch shape (tn %d, nblk %d, spw %d)", tn, nblk, SPW); return WM_ERR_INVALID; }
@@ -1094,6 +1064,12 @@ static void pick_shape(int epi, bool ln, int spw, int nw, int B, int n_tiles, in
     // 512, register budget) or more than 8 k-steps per wave (K = 4d at d = 576 / 640: spw 12 / 10 on <= 8 waves -- the
     // two-block kernel holds 2 x SPW activation fragments and exists for SPW <= 8 only): one unit per workgroup, more
     // workgroups along the batch
+    if (blocks < 2 && epi == DE_LOGITS && ln && spw <= 6) {
+        // the vocabulary product of a one-block group: 4 tiles per workgroup (810 workgroups instead of 3 242 two-wave
+        // ones; -1.4 % per position at tiny.en / base / small, neutral at large-v2: profiles/r04_latency_probe.txt)
+        *tn = (g_wm_tuning.logits_tn == 1 || g_wm_tuning.logits_tn == 2) ? g_wm_tuning.logits_tn : 4;
+        return;
+    }
     if (blocks < 2 || nw > 8 || spw > 8) return;
     *nblk = env_nb == 1 ? 1 : 2;
     const bool wide = ln && (epi == DE_QKV || epi == DE_GELU || epi == DE_LOGITS) && *nblk == 2 && spw <= 6;
@@ -1124,14 +1100,11 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     const bool ln = a.c1 != nullptr;
     WM_REQUIRE(!ln || (a.stats_in && a.K % 64 == 0 && a.K / 16 <= 80), WM_ERR_INVALID,
                "dec_gemv: LayerNorm mode needs the producer's K/16 partial statistics (K a multiple of 64, <= 1280)");
-    WM_REQUIRE((a.a != nullptr || a.att_part != nullptr) && a.W != nullptr, WM_ERR_INVALID, "dec_gemv: null operand");
+    WM_REQUIRE(a.a != nullptr && a.W != nullptr, WM_ERR_INVALID, "dec_gemv: null operand");
     DecGemvDev p;
     memset(&p, 0, sizeof(p));
     p.B = a.B; p.N = a.N; p.K = a.K;
     p.W = a.W; p.c1 = a.c1; p.c2 = a.c2; p.a = a.a;
-    p.att_part = a.att_part; p.att_heads = a.att_heads;
-    WM_REQUIRE(!a.att_part || (a.epi == DE_RESID && !ln && a.B <= 16 && a.K == a.att_heads * 64), WM_ERR_INVALID,
-               "dec_gemv: merge-on-load is the out-projection of a split cross-attention (<= 16 rows, K = heads x 64)");
     p.stats_in = a.stats_in; p.stats_parts = a.K / 16; p.stats_out = a.stats_out;
     p.mean_in = a.mean_in; p.mean_out = a.mean_out;
     p.stats_stride = 2L * (a.epi == DE_RESID ? a.N : a.K);  // [parts <= d/16][16][2] floats per block of 16 rows
@@ -1222,8 +1195,7 @@ int wm_dec_attn_splits(int B, int H) {
 
 int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
                      int T_stride, int n_keys, const int *pos_ptr, int nsplit, float *part, bf16_t *att,
-                     bool cross, const bf16_t *pf_ptr, int pf_rows, int pf_k, const int *live_rows, const int *n_live,
-                     bool combine) {
+                     bool cross, const bf16_t *pf_ptr, int pf_rows, int pf_k, const int *live_rows, const int *n_live) {
     WM_REQUIRE(nsplit == 1 || nsplit == 2 || nsplit == 4 || nsplit == 8, WM_ERR_INVALID,
                "dec_attention: nsplit %d is not 1, 2, 4 or 8", nsplit);
     WM_REQUIRE(T_stride <= ATT_MAXK && n_keys <= ATT_MAXK, WM_ERR_INVALID,
@@ -1252,10 +1224,20 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
             // few pairs: deal the (pair, stream) units evenly over ~256 workgroups (see the kernel)
             const int units = B * H * 8;
             int wpw = (units + 255) / 256;
-            wpw = wpw < 1 ? 1 : (wpw > 8 ? 8 : wpw);
+            wpw = wpw < 1 ? 1 : (wpw > 4 ? 4 : wpw);   // < 96 pairs = < 768 units: <= 3 (the DEEP kernel is built for <= 4 waves)
             const int g = (units + wpw - 1) / wpw;
-            dec_rows_attn_kernel<8, 4, WM_XATTN_NT><<<g, wpw * 64, 0, ctx->stream>>>(
-                q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, 8, B * H, g, nullptr, 0, wpw, live_rows, n_live);
+            // (DEEP: every block of a stream requested up front -- the flat deal is the latency regime by construction)
+            if (g_wm_tuning.xattn_no_deep)
+                dec_rows_attn_kernel<8, 4, WM_XATTN_NT><<<g, wpw * 64, 0, ctx->stream>>>(
+                    q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, 8, B * H, g, nullptr, 0, wpw, live_rows, n_live);
+            // a cache of <= 3.2 MB per layer (tiny.en / base, single chunk) stays in the L2s from one position to the next
+            // when it is read with cacheable loads: -1 .. -2 % per position there; +5 % at `small` (4.6 MB): the rule
+            else if ((size_t)B * H * T_stride * 64 * 2 * 2 <= (size_t)3200 * 1024)
+                dec_rows_attn_kernel<8, 4, false, true><<<g, wpw * 64, 0, ctx->stream>>>(
+                    q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, 8, B * H, g, nullptr, 0, wpw, live_rows, n_live);
+            else
+                dec_rows_attn_kernel<8, 4, WM_XATTN_NT, true><<<g, wpw * 64, 0, ctx->stream>>>(
+                    q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, 8, B * H, g, nullptr, 0, wpw, live_rows, n_live);
         } else {
             dim3 grid(gx, nsplit);
             // ONE cross-attention workgroup per CU, chip-wide: a workgroup reserves more than half of the CU's 160 KB of
@@ -1278,7 +1260,7 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
         }
         WM_HIP(hipGetLastError());
     }
-    if (nsplit > 1 && combine) {   // (combine == false: the consumer merges the partials itself, DecGemvArgs::att_part)
+    if (nsplit > 1) {
         WmProfScope ps(&ctx->prof, "dec_attn_combine", ctx->stream);
         dec_attn_combine_kernel<8><<<B * H, 64, 0, ctx->stream>>>(part, H, H * 64, att);
         WM_HIP(hipGetLastError());

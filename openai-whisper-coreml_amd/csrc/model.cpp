@@ -613,17 +613,10 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.mean_in = mean_buf(cur); a.mean_out = mean_buf(cur ^ 1); cur ^= 1;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 5. cross-attention over the 1500 cached encoder frames
-        //    (a SPLIT launch -- few pairs -- leaves its stream partials to the out-projection, which merges them on load:
-        //    no combine launch)
-        int spw_d = 0;
-        (void)wm_dec_gemv_split(d, &spw_d);   // the merging GEMV exists for two k-steps per wave (d <= 512: tiny, base)
-        const bool merge_on_load = xns > 1 && B <= 16 && spw_d == 2 && !g_wm_tuning.no_merge_on_load;
-        WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, xns, m->dpart, m->datt, true, L.wxo, d, d, live, nlive,
-                                !merge_on_load));
+        WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, xns, m->dpart, m->datt, true, L.wxo, d, d, live, nlive));
         // 6. out-projection + residual
         memset(&a, 0, sizeof(a));
         a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wxo; a.c2 = L.bxo;
-        if (merge_on_load) { a.att_part = m->dpart; a.att_heads = H; }
         a.a = m->datt; a.out_f32 = m->dx; a.out_bf16 = m->dxb; a.ldo = d; a.stats_out = m->dstats;
         a.mean_in = mean_buf(cur);
         a.pf_ptr = L.w1_f; a.pf_rows = 4 * d; a.pf_k = d;

@@ -256,8 +256,6 @@ struct DecGemvArgs {
     const float *c1;    // LayerNorm mode (non-null): column sums of the folded weights, see DecLayerW
     const float *c2;    // [N] bias (LayerNorm mode: + beta fold) or null
     const bf16_t *a;    // [B padded to 16][K] bf16 activations in WL_TILED order (wm_tiled_offset(b, k, K))
-    const float *att_part;  // instead of `a` (DE_RESID, <= 16 rows): cross-attention stream partials [B][att_heads][8][66],
-    int att_heads;          //   merged on load with the combine launch's arithmetic (wm_dec_attention(..., combine = false))
     const float *stats_in; // LayerNorm mode: [B/16][K/16][16][2] partial (sum, sum of squares) per row of the f32 residual,
     int stats_parts;       //                 from the producer of the residual (always K/16 parts; unused ones are zero)
     float *stats_out;      // DE_RESID: [B/16][N/16][16][2] partials of the updated residual (may be null)
@@ -299,7 +297,7 @@ int wm_dec_attn_splits(int B, int H);
 int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
                      int T_stride, int n_keys, const int *pos_ptr, int nsplit, float *part, bf16_t *att,
                      bool cross, const bf16_t *pf_ptr = nullptr, int pf_rows = 0, int pf_k = 0,
-                     const int *live_rows = nullptr, const int *n_live = nullptr, bool combine = true);
+                     const int *live_rows = nullptr, const int *n_live = nullptr);
 // The decoder's causal self-attention (<= 448 cached rows per pair): one 4-wave workgroup per (sequence, head).
 int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H, int T_stride,
                           int n_keys, const int *pos_ptr, bf16_t *att, const bf16_t *pf_ptr = nullptr, int pf_rows = 0,

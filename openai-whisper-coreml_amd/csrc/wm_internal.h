@@ -169,7 +169,7 @@ struct WmTuning {
     int gemm_tile = 0;            // force the encoder GEMM tile (128 / 256)
     int gemm_gm = 4;              // grouped tile order of the encoder GEMM
     int no_early_stop = 0;        // 1: decode every position and truncate on the host (the round-2 behaviour)
-    int no_merge_on_load = 0;     // 1: a split cross-attention is followed by its combine launch (rounds 2-3) instead of
-                                  //    the out-projection merging the stream partials on load
+    int logits_tn = 0;            // 1 / 2: tiles per workgroup of the logits product at <= 16 rows (product: 4)
+    int xattn_no_deep = 0;        // 1: the flat (few-pair) cross-attention walks its blocks one round trip at a time
 };
 extern WmTuning g_wm_tuning;   // api.cpp
