@@ -321,6 +321,9 @@ def main():
                          "(sharding.partition: 120 chunks = 1 h -> 15 per GPU at 8 GPUs, BASELINE.json configs[4]); a step "
                          "is then one pass over the whole job and --batch is ignored.  Must be divisible by --gpus.")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the other BASELINE.json configurations")
+    ap.add_argument("--tuning", default="",
+                    help="EXPERIMENTS ONLY: key=value,... launch-shape knobs (wmdbg_set_tuning).  Loads the DEBUG library "
+                         "instead of the product -- the product has no such knobs -- and marks the line \"experimental\".")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-early-stop", action="store_true", help="skip the additional early-stop workload")
     ap.add_argument("--no-single-batch", action="store_true",
@@ -356,8 +359,15 @@ def main():
     B = pkg.binding
     sharding = importlib.import_module("openai_whisper_coreml_amd.sharding")
     dims = B.MODEL_DIMS[args.model]
+    tuning = dict(kv.split("=") for kv in args.tuning.split(",") if kv)
+    if tuning:
+        dbg = B.load_debug_library()
+        dbg.wmdbg_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        for k, v in tuning.items():
+            if dbg.wmdbg_set_tuning(k.encode(), int(v)) != 0:
+                raise SystemExit("unknown tuning key %r" % k)
     # WM_BENCH_LOCAL_DEVICE: device ordinal override (two ranks sharing one GPU in the one-GPU-box test)
-    ctx = B.Context(dims, device=int(os.environ.get("WM_BENCH_LOCAL_DEVICE", local_rank)))
+    ctx = B.Context(dims, device=int(os.environ.get("WM_BENCH_LOCAL_DEVICE", local_rank)), debug=bool(tuning))
     ctx.init_synthetic(20240928, matrix_gain=args.weight_gain)
     ctx.finalize()
 
@@ -645,6 +655,7 @@ def main():
             "distinct_tokens_per_row": {"min": int(min(per_row)) if per_row else 0,
                                         "mean": float(np.mean(per_row)) if per_row else 0.0},
             "weight_gain": args.weight_gain,
+            "experimental": {"debug_library": True, "tuning": tuning} if tuning else None,
             # the literal BASELINE.json configs[3] figure: ONE batch of %d chunks in flight, nothing else on the GPU
             "value_batch8": (30.0 * nb / (single_ms * 1e-3)) if single_ms else None,
             "single_batch_latency_ms": single_ms,

@@ -16,6 +16,7 @@
 #include "model.h"
 
 WmTuning g_wm_tuning;   // wm_internal.h: defaults = the product; only the debug library has a setter
+std::atomic<int> g_wm_active_decodes[64];
 
 // ---------------------------------------------------------------- errors -------------
 static thread_local std::string g_last_error;

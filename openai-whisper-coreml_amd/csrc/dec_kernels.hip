@@ -1195,7 +1195,8 @@ int wm_dec_attn_splits(int B, int H) {
 
 int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
                      int T_stride, int n_keys, const int *pos_ptr, int nsplit, float *part, bf16_t *att,
-                     bool cross, const bf16_t *pf_ptr, int pf_rows, int pf_k, const int *live_rows, const int *n_live) {
+                     bool cross, const bf16_t *pf_ptr, int pf_rows, int pf_k, const int *live_rows, const int *n_live,
+                     bool short_lived) {
     WM_REQUIRE(nsplit == 1 || nsplit == 2 || nsplit == 4 || nsplit == 8, WM_ERR_INVALID,
                "dec_attention: nsplit %d is not 1, 2, 4 or 8", nsplit);
     WM_REQUIRE(T_stride <= ATT_MAXK && n_keys <= ATT_MAXK, WM_ERR_INVALID,
@@ -1207,7 +1208,8 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
         // CU (a second cross-attention workgroup does not: LDS reservation below); at most 256 workgroups -- one per CU --
         // walk the pairs, balanced (56 chunks x 20 heads = 224 workgroups x 5 pairs).  Measured alone at B = 8 / 56 / 128:
         // 12.8 / 67 / 144 us (4.8 / 6.4 / 6.8 TB/s: ~6.4 is what HBM reads deliver).
-        const int cap = g_wm_tuning.xattn_wgs > 0 ? g_wm_tuning.xattn_wgs : 256;
+        // short_lived (the chip is shared with other decode groups): one workgroup per pair, see WmModel::xattn_shared
+        const int cap = short_lived ? (1 << 30) : (g_wm_tuning.xattn_wgs > 0 ? g_wm_tuning.xattn_wgs : 256);
         int n_wg = B * H;
         if (n_wg > cap) {
             const int rounds = (n_wg + cap - 1) / cap;

@@ -84,12 +84,7 @@ WmStopDev wm_model_stop_dev(const WmModel *m) {
 }
 
 void wm_model_drop_graphs(WmModel *m) {
-    for (WmModel::GraphSet &g : m->graph_sets) {
-        if (g.e1) (void)hipGraphExecDestroy(g.e1);
-        if (g.g1) (void)hipGraphDestroy(g.g1);
-        if (g.ek) (void)hipGraphExecDestroy(g.ek);
-        if (g.gk) (void)hipGraphDestroy(g.gk);
-    }
+    for (WmModel::GraphSet &g : m->graph_sets) g.destroy();
     m->graph_sets.clear();
     m->graph_cur = -1;
 }
@@ -556,6 +551,7 @@ int wm_model_decode_begin(wm_ctx *ctx, int B) {
     // (an error in the middle of a step) must not leave the next one with a stale count
     WM_HIP(hipMemsetAsync(m->darrive, 0, sizeof(int), ctx->stream));
     m->stop_on = false;   // wm_transcribe_greedy switches it on for its own decode (lane_prefill)
+    m->xattn_shared = false;   // ... and decides whether the group shares the chip
     return WM_OK;
 }
 
@@ -613,7 +609,8 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.mean_in = mean_buf(cur); a.mean_out = mean_buf(cur ^ 1); cur ^= 1;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 5. cross-attention over the 1500 cached encoder frames
-        WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, xns, m->dpart, m->datt, true, L.wxo, d, d, live, nlive));
+        WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, xns, m->dpart, m->datt, true, L.wxo, d, d, live, nlive,
+                                m->xattn_shared && !g_wm_tuning.xattn_never_short));
         // 6. out-projection + residual
         memset(&a, 0, sizeof(a));
         a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wxo; a.c2 = L.bxo;

@@ -141,6 +141,12 @@ struct WmModel {
     // early stop (wm_transcribe_greedy with eot >= 0 or per-chunk token budgets): see WmStopDev
     int *ddone = nullptr, *dbudget = nullptr, *dlive = nullptr, *dnlive = nullptr;
     int *h_nlive = nullptr;     // pinned host ring: n_live after each burst of positions (the host polls it)
+    // The decode group being enqueued SHARES the chip with other groups (other lanes of the call, other contexts' calls):
+    // its cross-attention is launched as one short-lived workgroup per (sequence, head) pair instead of <= 256 persistent
+    // ones.  Alone, the persistent shape streams faster (56 rows: 66.8 vs 70.5 us); next to other groups' kernels the
+    // short-lived one lets their workgroups in every ~13 us instead of once per launch: driver command 2076 -> 2100-2134
+    // audio-s/s, default run 2190 -> 2250 (profiles/r04_xattn_short_lived.txt).  A launch shape: same bits.
+    bool xattn_shared = false;
     bool stop_on = false;       // the decode being enqueued uses the stop state (kernel arguments of the captured graph)
     bool budget_on = false;
     int stop_eot = -1;
@@ -152,9 +158,22 @@ struct WmModel {
     // pass to the next) instead of re-capturing ~2300 launches every time the shape changes (measured: the capture is
     // host work of a few ms that hides behind the lane's own encoder, so this is tidiness, not throughput).
     struct GraphSet {
-        int B = 0, n_prompt = 0, cap_b = 0, mask = 0, stop_key = 0, burst = 0;
-        hipGraph_t g1 = nullptr, gk = nullptr;
-        hipGraphExec_t e1 = nullptr, ek = nullptr;
+        int B = 0, n_prompt = 0, cap_b = 0, mask = 0, stop_key = 0;
+        // [mode]: 0 = the group has the chip to itself, 1 = it shares it (xattn_shared: short-lived cross-attention
+        // workgroups); chosen burst by burst from the number of decodes in flight on the device, captured on first use
+        int burst[2] = {0, 0};
+        hipGraph_t g1[2] = {nullptr, nullptr}, gk[2] = {nullptr, nullptr};
+        hipGraphExec_t e1[2] = {nullptr, nullptr}, ek[2] = {nullptr, nullptr};
+        void destroy() {
+            for (int i = 0; i < 2; ++i) {
+                if (e1[i]) (void)hipGraphExecDestroy(e1[i]);
+                if (g1[i]) (void)hipGraphDestroy(g1[i]);
+                if (ek[i]) (void)hipGraphExecDestroy(ek[i]);
+                if (gk[i]) (void)hipGraphDestroy(gk[i]);
+                e1[i] = ek[i] = nullptr;
+                g1[i] = gk[i] = nullptr;
+            }
+        }
         unsigned long stamp = 0;   // last use (LRU eviction)
     };
     static constexpr int kMaxGraphSets = 4;
@@ -297,7 +316,7 @@ int wm_dec_attn_splits(int B, int H);
 int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H,
                      int T_stride, int n_keys, const int *pos_ptr, int nsplit, float *part, bf16_t *att,
                      bool cross, const bf16_t *pf_ptr = nullptr, int pf_rows = 0, int pf_k = 0,
-                     const int *live_rows = nullptr, const int *n_live = nullptr);
+                     const int *live_rows = nullptr, const int *n_live = nullptr, bool short_lived = false);
 // The decoder's causal self-attention (<= 448 cached rows per pair): one 4-wave workgroup per (sequence, head).
 int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t *vc, int B, int H, int T_stride,
                           int n_keys, const int *pos_ptr, bf16_t *att, const bf16_t *pf_ptr = nullptr, int pf_rows = 0,

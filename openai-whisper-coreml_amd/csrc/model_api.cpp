@@ -458,12 +458,13 @@ int capture_positions(LaneJob &j, int n_prompt, int n_pos, hipGraph_t *g, hipGra
     return WM_OK;
 }
 
-int lane_graph(LaneJob &j, int n_prompt, int n_steps) {
+// Select (creating it if needed) the graph set of the lane's current decode shape.  The graphs themselves are captured
+// on first use, per sharing mode, by lane_burst.
+int lane_graph(LaneJob &j, int n_prompt) {
     wm_ctx *c = j.c;
     WmModel *m = c->model;
     const int mk = (m->mask_on ? 1 : 0) | (m->ts_on ? 2 : 0);
     const int sk = m->stop_on ? (1 | (m->budget_on ? 2 : 0) | ((m->stop_eot + 2) << 2)) : 0;
-    const int K = burst_len();
     int cur = -1;
     for (size_t i = 0; i < m->graph_sets.size(); ++i) {
         const WmModel::GraphSet &g = m->graph_sets[i];
@@ -474,11 +475,7 @@ int lane_graph(LaneJob &j, int n_prompt, int n_steps) {
             size_t old = 0;
             for (size_t i = 1; i < m->graph_sets.size(); ++i)
                 if (m->graph_sets[i].stamp < m->graph_sets[old].stamp) old = i;
-            WmModel::GraphSet &g = m->graph_sets[old];
-            if (g.e1) (void)hipGraphExecDestroy(g.e1);
-            if (g.g1) (void)hipGraphDestroy(g.g1);
-            if (g.ek) (void)hipGraphExecDestroy(g.ek);
-            if (g.gk) (void)hipGraphDestroy(g.gk);
+            m->graph_sets[old].destroy();
             m->graph_sets.erase(m->graph_sets.begin() + (long)old);
         }
         WmModel::GraphSet g;
@@ -487,35 +484,37 @@ int lane_graph(LaneJob &j, int n_prompt, int n_steps) {
         cur = (int)m->graph_sets.size() - 1;
     }
     m->graph_cur = cur;
-    WmModel::GraphSet &g = m->graph_sets[cur];
-    g.stamp = ++m->graph_clock;
-    if (!g.e1) {
-        const int rc = capture_positions(j, n_prompt, 1, &g.g1, &g.e1);
-        if (rc != WM_OK) { g.g1 = nullptr; g.e1 = nullptr; return rc; }
-    }
-    if (K > 1 && n_steps >= K && (!g.ek || g.burst != K)) {
-        if (g.ek) { (void)hipGraphExecDestroy(g.ek); g.ek = nullptr; }
-        if (g.gk) { (void)hipGraphDestroy(g.gk); g.gk = nullptr; }
-        const int rc = capture_positions(j, n_prompt, K, &g.gk, &g.ek);
-        if (rc != WM_OK) { g.gk = nullptr; g.ek = nullptr; return rc; }
-        g.burst = K;
-    }
+    m->graph_sets[cur].stamp = ++m->graph_clock;
     return WM_OK;
 }
 
-// enqueue the next burst of positions of a lane (<= burst_len(), up to the end of the sequence)
-int lane_burst(LaneJob &j, int n_prompt, int n_steps, bool use_graph, bool stop_on) {
+// enqueue the next burst of positions of a lane (<= burst_len(), up to the end of the sequence).  `shared`: other decode
+// groups are in flight on the device right now -- this burst's cross-attention launches are the short-lived shape.
+int lane_burst(LaneJob &j, int n_prompt, int n_steps, bool use_graph, bool stop_on, bool shared) {
     wm_ctx *c = j.c;
     WmModel *m = c->model;
     const int K = burst_len();
     const int k = n_steps - j.t < K ? n_steps - j.t : K;
-    const WmModel::GraphSet *g = use_graph ? &m->graph_sets[m->graph_cur] : nullptr;
-    if (use_graph && k == K && K > 1 && g->ek && g->burst == K) {
-        WM_HIP(hipGraphLaunch(g->ek, c->stream));
+    const int mode = shared ? 1 : 0;
+    m->xattn_shared = shared;   // read by wm_model_decode_step (eager launches and captures alike)
+    WmModel::GraphSet *g = use_graph ? &m->graph_sets[m->graph_cur] : nullptr;
+    if (use_graph && k == K && K > 1) {
+        if (!g->ek[mode] || g->burst[mode] != K) {
+            if (g->ek[mode]) { (void)hipGraphExecDestroy(g->ek[mode]); g->ek[mode] = nullptr; }
+            if (g->gk[mode]) { (void)hipGraphDestroy(g->gk[mode]); g->gk[mode] = nullptr; }
+            const int rc = capture_positions(j, n_prompt, K, &g->gk[mode], &g->ek[mode]);
+            if (rc != WM_OK) { g->gk[mode] = nullptr; g->ek[mode] = nullptr; return rc; }
+            g->burst[mode] = K;
+        }
+        WM_HIP(hipGraphLaunch(g->ek[mode], c->stream));
     } else {
+        if (use_graph && !g->e1[mode]) {
+            const int rc = capture_positions(j, n_prompt, 1, &g->g1[mode], &g->e1[mode]);
+            if (rc != WM_OK) { g->g1[mode] = nullptr; g->e1[mode] = nullptr; return rc; }
+        }
         for (int i = 0; i < k; ++i) {
             if (use_graph) {
-                WM_HIP(hipGraphLaunch(g->e1, c->stream));
+                WM_HIP(hipGraphLaunch(g->e1[mode], c->stream));
             } else {
                 WM_TRY(wm_model_decode_step(c, j.Bg, false, 0, m->dims.n_vocab - 1, m->mask_on ? n_prompt - 1 : -1, m->ts_on));
                 WM_TRY(wm_model_close_step(c, j.Bg, n_prompt, true, nullptr, 0, m->ts_on));
@@ -587,6 +586,12 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
     }
     ctx->stage_ms[0] = ctx->stage_ms[1] = ctx->stage_ms[2] = 0.f;
     const int n_steps = n_prompt + max_new - 1;
+    // decodes in flight on this device (this call included): other lanes of this call, other contexts' calls
+    struct ActiveGuard {
+        std::atomic<int> &n;
+        explicit ActiveGuard(std::atomic<int> &a) : n(a) { n.fetch_add(1, std::memory_order_relaxed); }
+        ~ActiveGuard() { n.fetch_sub(1, std::memory_order_relaxed); }
+    } active_guard(g_wm_active_decodes[ctx->device & 63]);
     const int base = B / G, rem = B % G;
     int next_group = 0, groups_done = 0;
     while (groups_done < G) {
@@ -601,7 +606,7 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
                 j.b0 = g * base + (g < rem ? g : rem);
                 j.t = 0; j.bursts = 0; j.stopped = false;
                 WM_TRY(lane_prefill(j, pcm, pcm_dtype, prompt, n_prompt, mem, stop));
-                if (use_graph) WM_TRY(lane_graph(j, n_prompt, n_steps));
+                if (use_graph) WM_TRY(lane_graph(j, n_prompt));
                 j.state = LaneJob::DECODING;
                 progress = true;
                 continue;   // the other lanes get their prefill before anyone's first burst
@@ -617,7 +622,11 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
                     if (j.c->model->h_nlive[slot] == 0) j.stopped = true;
                 }
                 if (j.t < n_steps && !j.stopped) {
-                    WM_TRY(lane_burst(j, n_prompt, n_steps, use_graph, stop.on));
+                    // does this burst share the chip?  other lanes of this call still decoding, or other calls in flight
+                    int busy = 0;
+                    for (int o = 0; o < n_lanes; ++o) busy += jobs[o].state == LaneJob::DECODING && jobs[o].t < n_steps;
+                    const bool shared = busy > 1 || g_wm_active_decodes[ctx->device & 63].load(std::memory_order_relaxed) > 1;
+                    WM_TRY(lane_burst(j, n_prompt, n_steps, use_graph, stop.on, shared));
                     progress = true;
                     continue;
                 }

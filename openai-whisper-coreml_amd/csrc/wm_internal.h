@@ -170,6 +170,12 @@ struct WmTuning {
     int gemm_gm = 4;              // grouped tile order of the encoder GEMM
     int no_early_stop = 0;        // 1: decode every position and truncate on the host (the round-2 behaviour)
     int logits_tn = 0;            // 1 / 2: tiles per workgroup of the logits product at <= 16 rows (product: 4)
+    int xattn_never_short = 0;    // 1: persistent cross-attention workgroups also when the chip is shared (rounds 2-3)
     int xattn_no_deep = 0;        // 1: the flat (few-pair) cross-attention walks its blocks one round trip at a time
 };
 extern WmTuning g_wm_tuning;   // api.cpp
+
+// wm_transcribe_greedy calls in flight per device (any context, any host thread): a decode group that shares the chip
+// with others launches its cross-attention as short-lived workgroups (model.h WmModel::xattn_shared).
+#include <atomic>
+extern std::atomic<int> g_wm_active_decodes[64];   // api.cpp
