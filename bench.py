@@ -583,12 +583,17 @@ def main():
                     c.sync()
                 insitu_wall_ms = (time.perf_counter() - t_i0) * 1e3
                 tot_ms, tot_n = 0.0, 0
+                fam_all = {}
                 for c in ctxs:
                     pf = c.profile()
                     c.profile_enable(False)
                     if dom in pf:
                         tot_ms += pf[dom]["ms"]
                         tot_n += pf[dom]["n"]
+                    for k_, v_ in pf.items():
+                        a_ = fam_all.setdefault(k_, [0.0, 0])
+                        a_[0] += v_["ms"]
+                        a_[1] += v_["n"]
                 if tot_n:
                     us = max(tot_ms / tot_n * 1e3 - ev_over, 1e-3)
                     # mean algorithmic work per launch over the plan's groups (they differ by at most one batch)
@@ -597,6 +602,9 @@ def main():
                     peak = HBM_PEAK_GBS * 1e9 if kind == "hbm" else MFMA_BF16_PEAK_TF * 1e12
                     common["in_situ"] = {"lanes": S, "avg_us": us, "launches": tot_n, "frac": w_mean / (us * 1e-6) / peak,
                                          "wall_ms": insitu_wall_ms,
+                                         # every decode family's mean launch duration (event bias subtracted) in this pass
+                                         "families_avg_us": {k_: max(v_[0] / v_[1] * 1e3 - ev_over, 0.0)
+                                                             for k_, v_ in sorted(fam_all.items()) if k_.startswith(("dec_", "argmax")) and v_[1]},
                                          "note": "same plan, %d groups in flight, eager event-bracketed launches on every lane" % S}
             if kind == "hbm":
                 ach = work / avg_s / 1e9

@@ -52,10 +52,20 @@ def dump_stft(crate_dir):
     so = [p for p in so if p.endswith((".so", ".dylib"))]
     assert so, "cargo produced no cdylib under %s" % target
     lib = ctypes.CDLL(so[0])
+    out = stft_fixture(lib, "rust stft crate, cargo release build, realfft per Cargo.lock")
+    path = os.path.join(HERE, "ref_stft_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path)
+
+
+def stft_fixture(lib, source):
+    """The front-end fixture from ANY library that exports the reference's symbol (bridge.h:11).  dump_stft calls it with the
+    Rust crate's cdylib; tests/test_reference_goldens.py calls it with the ORACLE's library, so that a change of the schema
+    here -- or of what the consuming tests read -- is caught on the CPU, before anyone with cargo runs this script."""
     lib.generate_spectrogram.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     lib.generate_spectrogram.restype = None
     frames = sampled_frames()
-    out = {"frames": frames, "source": np.array("rust stft crate, cargo release build, realfft per Cargo.lock")}
+    out = {"frames": frames, "source": np.array(source)}
     cases = {"noise0": L.synth_chunk(0), "noise1": L.synth_chunk(1), "zeros": np.zeros(480000, np.float32),
              "ones": np.ones(480000, np.float32)}
     for name, x in cases.items():
@@ -68,9 +78,7 @@ def dump_stft(crate_dir):
         out[name + "_sum"] = np.array([y.sum(), np.abs(y).sum(), (y * y).sum(), y.max(), y.min()])
         out[name + "_pad_head"] = buf[:200].copy()            # lib.rs:34-40 mutates the caller's buffer
         out[name + "_pad_tail"] = buf[480200:].copy()
-    path = os.path.join(HERE, "ref_stft_golden.npz")
-    np.savez_compressed(path, **out)
-    print("wrote", path)
+    return out
 
 
 def dump_whisper(name):
@@ -92,17 +100,24 @@ def dump_whisper(name):
         sot = 50258 if dims["n_vocab"] >= 51865 else 50257
         toks = torch.tensor([[sot, sot + 1, sot + 101, sot + 105]]) if dims["n_vocab"] >= 51865 else torch.tensor([[50257, 50362]])
         logits = model.decoder(toks, xa)
-    rows = np.array([0, 1, 2, 3, 100, 500, 749, 750, 1000, 1496, 1497, 1498, 1499])
-    out = {"model": np.array(name), "dims_keys": np.array(sorted(dims)), "dims_vals": np.array([dims[k] for k in sorted(dims)]),
-           "state_sha256": np.array(h.hexdigest()), "mel": mel[0].numpy().astype(np.float32), "rows": rows,
-           "xa_rows": xa[0, rows].numpy(), "xa_sum": np.array([float(xa.sum()), float(xa.abs().sum())]),
-           "tokens": toks.numpy().astype(np.int32), "logits_lang": logits[0, 0, 50259:50358].numpy() if dims["n_vocab"] >= 51865 else np.zeros(0),
-           "logits_head": logits[0, :, :256].numpy(), "logits_argmax": logits[0].argmax(-1).numpy(),
-           "logits_sum": np.array([float(logits.sum()), float(logits.abs().sum())])}
+    out = model_fixture(name, dims, h.hexdigest(), mel[0].numpy(), xa.numpy(), toks.numpy(), logits.numpy())
     path = os.path.join(HERE, "ref_whisper_%s_golden.npz" % name.replace(".", "_"))
     np.savez_compressed(path, **out)
     print("wrote", path, "-- convert the same checkpoint with openai-whisper-coreml_amd/weights.py:convert_openai_pt and set "
           "WM_REF_WEIGHTS=<flat file> so that tests/test_reference_goldens.py can load it")
+
+
+def model_fixture(name, dims, state_sha256, mel, xa, toks, logits):
+    """The model fixture from numpy arrays: mel (n_mels, 3000), xa (1, 1500, d), toks (1, T), logits (1, T, n_vocab).
+    dump_whisper fills it from openai-whisper; the CPU schema test fills it from the oracle."""
+    rows = np.array([0, 1, 2, 3, 100, 500, 749, 750, 1000, 1496, 1497, 1498, 1499])
+    return {"model": np.array(name), "dims_keys": np.array(sorted(dims)), "dims_vals": np.array([dims[k] for k in sorted(dims)]),
+            "state_sha256": np.array(state_sha256), "mel": np.asarray(mel, np.float32), "rows": rows,
+            "xa_rows": xa[0, rows], "xa_sum": np.array([float(xa.sum()), float(np.abs(xa).sum())]),
+            "tokens": np.asarray(toks, np.int32),
+            "logits_lang": logits[0, 0, 50259:50358] if dims["n_vocab"] >= 51865 else np.zeros(0),
+            "logits_head": logits[0, :, :256], "logits_argmax": logits[0].argmax(-1),
+            "logits_sum": np.array([float(logits.sum()), float(np.abs(logits).sum())])}
 
 
 if __name__ == "__main__":
