@@ -100,7 +100,7 @@ WM_API int wm_set_tensor(wm_ctx *ctx, const char *name, const float *data, size_
 /* Read a parameter back as f32 (the value the kernels use, i.e. after bf16 rounding for
  * matrix weights). */
 WM_API int wm_get_tensor(wm_ctx *ctx, const char *name, float *data, size_t n_elems);
-/* Flat weight file written by openai-whisper-coreml_amd/weights.py (format in DESIGN.md). */
+/* Flat weight file written by openai-whisper-coreml_amd/weights.py (format: the docstring of weights.py). */
 WM_API int wm_load_weights(wm_ctx *ctx, const char *path);
 /* Deterministic synthetic weights generated ON DEVICE (hash-based, approx N(0, std^2));
  * identical values to weights.synthetic_state_dict(dims, seed) on the host. */

@@ -86,7 +86,7 @@ extern "C" int wm_get_dims(const wm_ctx *ctx, wm_dims *out) try {
     return WM_OK;
 } WM_API_CATCH
 
-// Flat weight file (format: openai-whisper-coreml_amd/weights.py / DESIGN.md).
+// Flat weight file (format: the docstring of openai-whisper-coreml_amd/weights.py).
 extern "C" int wm_load_weights(wm_ctx *ctx, const char *path) try {
     WM_MODEL(ctx);
     WM_REQUIRE(path, WM_ERR_INVALID, "null path");
@@ -319,7 +319,7 @@ extern "C" int wm_set_token_budgets(wm_ctx *ctx, const int32_t *budgets, int n) 
 
 // ---------------------------------------------------------------- greedy transcription
 // One batch's decode is a chain of ~260 dependent launches per position and is bound by launch latency, not by
-// HBM, so a call with more chunks than one decode group is spread over LANES: weight-sharing
+// HBM (NOTEBOOK.md section 4), so a call with more chunks than one decode group is spread over LANES: weight-sharing
 // clones of the context (wm_clone), each with its own stream, activations, KV caches and decode graphs.  The
 // single host thread drives the lanes as a small non-blocking scheduler: a lane takes the next decode group as soon as
 // it has finished its previous one, positions are enqueued in BURSTS (one hipGraph of WM_BURST consecutive positions --
