@@ -24,7 +24,7 @@ extern "C" int wmdbg_set_tuning(const char *key, int value) {
         {"xattn_wgs", &g_wm_tuning.xattn_wgs}, {"xattn_no_flat", &g_wm_tuning.xattn_no_flat},
         {"xattn_lds_pad", &g_wm_tuning.xattn_lds_pad}, {"xattn_splits", &g_wm_tuning.xattn_splits},
         {"gemm_tile", &g_wm_tuning.gemm_tile}, {"gemm_gm", &g_wm_tuning.gemm_gm}, {"no_early_stop", &g_wm_tuning.no_early_stop},
-        {"xattn_no_deep", &g_wm_tuning.xattn_no_deep}, {"xattn_never_short", &g_wm_tuning.xattn_never_short},         {"logits_tn", &g_wm_tuning.logits_tn},
+        {"xattn_no_deep", &g_wm_tuning.xattn_no_deep}, {"xattn_never_short", &g_wm_tuning.xattn_never_short},         {"logits_tn", &g_wm_tuning.logits_tn}, {"enc_attn_valu_sum", &g_wm_tuning.enc_attn_valu_sum},
     };
     if (strcmp(key, "reset") == 0) { g_wm_tuning = WmTuning(); return WM_OK; }
     for (auto &e : table)
@@ -138,7 +138,7 @@ extern "C" int wmdbg_enc_attention(wm_ctx *ctx, const float *q, const float *k, 
     auto bf = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); };
     for (size_t mrow = 0; mrow < M; ++mrow)
         for (int j = 0; j < d; ++j) {
-            qk[mrow * 2 * d + j] = bf(q[mrow * d + j]);
+            qk[mrow * 2 * d + j] = bf(q[mrow * d + j] * WM_ENC_QSCALE);   // the kernel's contract: pre-scaled queries
             qk[mrow * 2 * d + d + j] = bf(k[mrow * d + j]);
         }
     for (int b = 0; b < B; ++b)

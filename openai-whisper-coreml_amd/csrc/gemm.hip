@@ -147,7 +147,7 @@ __device__ __forceinline__ void store_tile(const GemmDev &p, const f32x4 (&acc)[
                 if (EPI == EPI_XKV) {
                     ((bf16_t *)p.C)[roff + coff[j]] = f2bf(v);
                 } else if (EPI == EPI_QKV_ENC) {
-                    if (!vpart[j]) ((bf16_t *)p.C)[roff + n] = f2bf(v);
+                    if (!vpart[j]) ((bf16_t *)p.C)[roff + n] = f2bf(n < p.d_model ? v * WM_ENC_QSCALE : v);
                 } else if (EPI == EPI_BIAS_BF16) {
                     ((bf16_t *)p.C)[roff + n] = f2bf(v);
                 } else if (EPI == EPI_GELU_BF16) {
@@ -189,6 +189,7 @@ __device__ __forceinline__ void store_tile_staged(const GemmDev &p, const f32x4 
         coff = ((long)(kv * p.batch) * p.n_head + h) * p.seq * 64;
     }
     const unsigned rpb = (unsigned)p.c_rpb, seq = (unsigned)(p.seq > 0 ? p.seq : 1);
+    const bool qpart = EPI == EPI_QKV_ENC && nwave0 < p.d_model;   // a wave's 64 columns are inside one of q | k | v
     const int rrow = lane >> 3, chunk = lane & 7;
 #pragma unroll
     for (int ps = 0; ps < MI / 4; ++ps) {
@@ -200,6 +201,7 @@ __device__ __forceinline__ void store_tile_staged(const GemmDev &p, const f32x4 
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[ps * 4 + ii][j][r] + bv[j];
                     if (EPI == EPI_GELU_BF16) v = gelu_erf(v);
+                    if (EPI == EPI_QKV_ENC && qpart) v = v * WM_ENC_QSCALE;   // wave-uniform: the query third, see model.h
                     *(bf16_t *)(L + (ii * 16 + fq * 4 + r) * STAGE_ROW_BYTES + (j * 16 + frow) * 2) = f2bf(v);
                 }
         // row -> (batch, row-in-batch): ONE division per pass (the lane's first row), then 8 rows further per step

@@ -235,10 +235,13 @@ enum GemmEpi {
     EPI_GELU_BF16 = 1,  // C bf16 = gelu(acc + bias)
     EPI_RESID_F32 = 2,  // C f32 += acc + bias
     EPI_CONV2_F32 = 3,  // C f32 = gelu(acc + bias) + pos[m % rows_per_batch][n]
-    EPI_QKV_ENC = 4,    // n < 2d: C bf16 [m][2d];  n >= 2d: vt[b][h][e][s]
+    EPI_QKV_ENC = 4,    // n < 2d: C bf16 [m][2d] (query columns n < d multiplied by WM_ENC_QSCALE);  n >= 2d: vt[b][h][e][s]
     EPI_XKV = 5,        // cross K/V cache scatter
     EPI_F32 = 6         // C f32 = acc + bias (debug / generic)
 };
+// The encoder's queries are stored PRE-SCALED by hd^-1/2 * log2(e) (hd = 64): one f32 multiply in the QKV epilogue before
+// its single bf16 rounding, so that the attention kernel's score accumulators are exponents of 2 already (enc_kernels.hip).
+#define WM_ENC_QSCALE (0.125f * 1.44269504088896340736f)
 struct GemmArgs {
     const bf16_t *A;   // rows addressed as (m / a_rpb) * a_bstride + (m % a_rpb) * a_rstride
     long a_rpb, a_bstride, a_rstride;

@@ -1,134 +1,31 @@
-// enc_kernels.hip -- encoder-side kernels other than the GEMM (SURVEY.md section 2:
-// K6 LayerNorm, K8 encoder flash attention, plus the mel re-layout feeding conv1).
+// enc_attn_lab.hip -- standalone ablation lab for the encoder attention kernel (tools/, not product): the kernel text of
+// csrc/enc_kernels.hip with pieces switched off by a template mask, timed at large-v2 geometry.  Results of an ablated
+// variant are WRONG by construction; only the times mean something.
+//   ABL bits: 1 no QK^T MFMAs, 2 no exp, 4 no PV MFMAs, 8 no global->LDS staging, 16 no barrier, 32 never rescale
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/enc_attn_lab.hip -o tools/build/enc_attn_lab
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
 #include <type_traits>
-
-#include "model.h"
-
-namespace {
-
+#include <vector>
+typedef unsigned short bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
-
 __device__ __forceinline__ bf16_t f2bf(float f) {
     unsigned u = __float_as_uint(f);
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
-__device__ __forceinline__ unsigned pack2(float a, float b) {
-    return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16);
-}
-
-// ------------------------------------------------------------------ LayerNorm ----------
-// One wave64 per row, f32 statistics (eps 1e-5), two passes over registers.  HBM-bound:
-// reads d*4 B, writes d*2 B (bf16 GEMM operand) and/or d*4 B.
-template <int MAXP>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x,
-                                                        const float *__restrict__ g,
-                                                        const float *__restrict__ b, int rows, int d,
-                                                        bf16_t *__restrict__ ob, float *__restrict__ of) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    // 16 bytes per lane per load (one 1 KiB request per wave-instruction), all MAXP loads of the row in flight at once
-    const float4 *xr = (const float4 *)(x + (size_t)row * d);
-    const int np = d >> 2;  // float4 quads per row (d % 4 == 0, checked by the launcher)
-    float4 v[MAXP];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-        const int idx = i * 64 + lane;
-        v[i] = (idx < np) ? xr[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    const float mean = s / (float)d;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-        const int idx = i * 64 + lane;
-        if (idx < np) {
-            const float a = v[i].x - mean, c = v[i].y - mean, e = v[i].z - mean, f = v[i].w - mean;
-            q += (a * a + c * c) + (e * e + f * f);
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
-    const float rstd = rsqrtf(q / (float)d + 1e-5f);
-    const float4 *g4 = (const float4 *)g, *b4 = (const float4 *)b;
-#pragma unroll
-    for (int i = 0; i < MAXP; ++i) {
-        const int idx = i * 64 + lane;
-        if (idx < np) {
-            const float4 gg = g4[idx], bb = b4[idx];
-            const float y0 = (v[i].x - mean) * rstd * gg.x + bb.x;
-            const float y1 = (v[i].y - mean) * rstd * gg.y + bb.y;
-            const float y2 = (v[i].z - mean) * rstd * gg.z + bb.z;
-            const float y3 = (v[i].w - mean) * rstd * gg.w + bb.w;
-            if (ob) ((uint2 *)(ob + (size_t)row * d))[idx] = make_uint2(pack2(y0, y1), pack2(y2, y3));
-            if (of) ((float4 *)(of + (size_t)row * d))[idx] = make_float4(y0, y1, y2, y3);
-        }
-    }
-}
-
-// ------------------------------------------------------------------ mel re-layout -------
-// mel f32 [B][C][3000] (the reference's encoder input layout, Whisper.swift:25) ->
-// bf16 [B][3002][C] time-major with zero rows 0 and 3001 (zeroed once at allocation), so
-// conv1's 3-tap window of frame t is the contiguous run mel_t[b][t .. t+2][:].
-__global__ __launch_bounds__(256) void mel_time_major_kernel(const float *__restrict__ mel, int C,
-                                                             bf16_t *__restrict__ out) {
-    __shared__ float tile[128][65];
-    const int b = blockIdx.y, t0 = blockIdx.x * 64;
-    for (int i = threadIdx.x; i < C * 64; i += 256) {
-        const int c = i >> 6, t = i & 63;
-        tile[c][t] = (t0 + t < WM_N_FRAMES) ? mel[((size_t)b * C + c) * WM_N_FRAMES + t0 + t] : 0.f;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < C * 64; i += 256) {
-        const int t = i / C, c = i % C;
-        if (t0 + t < WM_N_FRAMES) out[((size_t)b * 3002 + 1 + t0 + t) * C + c] = f2bf(tile[c][t]);
-    }
-}
-
-__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restrict__ in,
-                                                          bf16_t *__restrict__ out, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        out[i] = f2bf(in[i]);
-}
-
-// ------------------------------------------------------------------ encoder attention ---
-// Non-causal multi-head attention, head_dim 64, flash style (online softmax, fp32
-// statistics, scores never leave registers).  One workgroup = 4 waves = 128 query rows of
-// one (chunk, head); each wave owns 32 query rows.
-//
-// CDNA4-specific structure: the score tile is computed TRANSPOSED, S^T = K Q^T, with
-// v_mfma_f32_32x32x16_bf16, so that lane l holds scores of ONE query (column l & 31):
-// the softmax row reductions are in-register max3 chains plus a single exchange with lane
-// l ^ 32 instead of butterfly shuffles.  P^T then feeds the second product directly as the
-// B operand of O^T = V^T P^T (no transpose, no LDS round trip for P); V is stored
-// transposed in HBM by the QKV GEMM epilogue so the A operand rows are contiguous, and the
-// kv order inside a k-step is whatever order the accumulator registers hold (both operands
-// use the same order, so the sum is unchanged).
-//
-// Round 4: the loop is bound by INSTRUCTION ISSUE, not by the matrix pipe (round 3: 16 MFMAs among ~200 instructions per
-// wave and 64-key tile, ~8 issue slots per 32-cycle MFMA => MFMA-busy 0.40), so the per-score VALU work was cut to the
-// two instructions that cannot go away (v_exp_f32, v_cvt_pk_bf16_f32):
-//   * the query arrives PRE-SCALED by hd^-1/2 log2(e) (one multiply in the QKV GEMM epilogue, before its single bf16
-//     rounding), and the running reference r of the online softmax enters the score product as the MFMA's C operand
-//     (a separate 16-register tuple holding -r): the accumulator comes out as s - r in log2 units, p = exp2(acc);
-//   * r is a LAGGED maximum: it moves (and O, l are rescaled, and the C tuple rewritten) only when a score of the tile
-//     exceeds it by more than 2^8 -- on the first tile, and rarely afterwards; p <= 256 is exact enough in bf16 / f32;
-//   * the row sum l is a fifth accumulator fed by the SAME bf16 P^T fragments against an all-ones A operand (4 MFMAs per
-//     tile instead of 16 packed adds + a cross-lane exchange): l sums exactly the probabilities O was built from.
+__device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
 constexpr int KS_STRIDE = 144;  // bytes per K row in LDS (128 + 16 pad): conflict-free b128
 constexpr int VS_STRIDE = 136;  // bytes per V^T row in LDS (128 + 8 pad): conflict-free b64
 constexpr float ATT_RESCALE_THR = 8.0f;   // log2 units: p <= 2^8 before the reference moves
 
-template <bool SUM_MFMA>
-__global__ __launch_bounds__(256, 3) void enc_attn_kernel(const bf16_t *__restrict__ qk,
+template <bool SUM_MFMA, int ABL, int OCC>
+__global__ __launch_bounds__(256, OCC) void enc_attn_kernel(const bf16_t *__restrict__ qk,
                                                           const bf16_t *__restrict__ vt,
                                                           bf16_t *__restrict__ att, int H, int S,
                                                           int S_pad, int d, int n_q, int n_bh) {
@@ -211,7 +108,7 @@ __global__ __launch_bounds__(256, 3) void enc_attn_kernel(const bf16_t *__restri
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr bool LAST = decltype(last_tag)::value;
         const int buf = j & 1;
-        if (!LAST) ATT_GLOAD_NEXT();
+        if (!LAST && !(ABL & 8)) ATT_GLOAD_NEXT();
         // ---- S^T - r = K Q^T + (-r) : two 32-kv blocks, the reference enters as the C operand -----------
         f32x16 st[2];
 #pragma unroll
@@ -220,7 +117,8 @@ __global__ __launch_bounds__(256, 3) void enc_attn_kernel(const bf16_t *__restri
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const bf16x8 kf = *(const bf16x8 *)(kp + s4 * 32);
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s4], s4 == 0 ? cneg : st[kb], 0, 0, 0);
+                if (!(ABL & 1)) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s4], s4 == 0 ? cneg : st[kb], 0, 0, 0);
+                else if (s4 == 0) { st[kb] = cneg; st[kb][0] += (float)kf[0]; }
             }
         }
         if constexpr (LAST) {  // mask kv >= S
@@ -239,7 +137,7 @@ __global__ __launch_bounds__(256, 3) void enc_attn_kernel(const bf16_t *__restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[kb][r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        if (FIRST || __builtin_amdgcn_ballot_w64(mloc > ATT_RESCALE_THR) != 0ull) {  // wave-uniform; rare after the first tile
+        if ((ABL & 32) ? FIRST : (FIRST || __builtin_amdgcn_ballot_w64(mloc > ATT_RESCALE_THR) != 0ull)) {  // wave-uniform; rare after the first tile
             const float delta = FIRST ? mloc : fmaxf(mloc, 0.f);   // the reference only moves up
             ref += delta;
 #pragma unroll
@@ -266,7 +164,7 @@ __global__ __launch_bounds__(256, 3) void enc_attn_kernel(const bf16_t *__restri
             for (int j2 = 0; j2 < 2; ++j2) {
                 f32x8 p8;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) p8[i] = __builtin_amdgcn_exp2f(st[kb][8 * j2 + i]);
+                for (int i = 0; i < 8; ++i) p8[i] = (ABL & 2) ? st[kb][8 * j2 + i] : __builtin_amdgcn_exp2f(st[kb][8 * j2 + i]);
                 const bf16x8 pf = __builtin_convertvector(p8, bf16x8);  // 4 x v_cvt_pk_bf16_f32
                 if (!SUM_MFMA) lsum_v += ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
                 const int kvoff = kb * 32 + 16 * j2 + 4 * hf;  // + {0..3} and + 8 + {0..3}
@@ -281,12 +179,13 @@ __global__ __launch_bounds__(256, 3) void enc_attn_kernel(const bf16_t *__restri
                         vf[i] = lo[i];
                         vf[4 + i] = hi[i];
                     }
-                    oacc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[eb], 0, 0, 0);
+                    if (!(ABL & 4)) oacc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[eb], 0, 0, 0);
+                    else oacc[eb][0] += (float)vf[0] + (float)pf[0];
                 }
                 if (SUM_MFMA) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
             }
-        if (!LAST) ATT_LSTORE(buf ^ 1);
-        __syncthreads();
+        if (!LAST && !(ABL & 8)) ATT_LSTORE(buf ^ 1);
+        if (!(ABL & 16)) __syncthreads();
     };
     if (ntiles == 1) {
         tile(0, std::true_type{}, std::true_type{});
@@ -311,50 +210,50 @@ __global__ __launch_bounds__(256, 3) void enc_attn_kernel(const bf16_t *__restri
     }
 }
 
-}  // namespace
 
-int wm_layernorm(wm_ctx *ctx, const float *x, const float *g, const float *b, int rows, int d,
-                 bf16_t *out_bf16, float *out_f32) {
-    WM_REQUIRE(d % 4 == 0 && d <= 1280, WM_ERR_INVALID, "layernorm: d=%d unsupported (a multiple of 4, <= 1280)", d);
-    WmProfScope ps(&ctx->prof, "layernorm", ctx->stream);
-    const int grid = (rows + 3) / 4;
-    if (d <= 256)
-        layernorm_kernel<1><<<grid, 256, 0, ctx->stream>>>(x, g, b, rows, d, out_bf16, out_f32);
-    else if (d <= 768)
-        layernorm_kernel<3><<<grid, 256, 0, ctx->stream>>>(x, g, b, rows, d, out_bf16, out_f32);
-    else
-        layernorm_kernel<5><<<grid, 256, 0, ctx->stream>>>(x, g, b, rows, d, out_bf16, out_f32);
-    WM_HIP(hipGetLastError());
-    return WM_OK;
-}
-
-int wm_mel_to_time_major(wm_ctx *ctx, const float *mel, int B, int n_mels, bf16_t *mel_t) {
-    WM_REQUIRE(n_mels <= 128, WM_ERR_INVALID, "n_mels > 128");
-    WmProfScope ps(&ctx->prof, "mel_time_major", ctx->stream);
-    dim3 grid((WM_N_FRAMES + 63) / 64, B);
-    mel_time_major_kernel<<<grid, 256, 0, ctx->stream>>>(mel, n_mels, mel_t);
-    WM_HIP(hipGetLastError());
-    return WM_OK;
-}
-
-int wm_f32_to_bf16(wm_ctx *ctx, const float *in, bf16_t *out, size_t n) {
-    const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    f32_to_bf16_kernel<<<grid, 256, 0, ctx->stream>>>(in, out, n);
-    WM_HIP(hipGetLastError());
-    return WM_OK;
-}
-
-int wm_enc_attention(wm_ctx *ctx, const bf16_t *qk, const bf16_t *vt, bf16_t *att, int B, int H,
-                     int S, int S_pad, int d) {
-    WM_REQUIRE(d == H * 64, WM_ERR_INVALID, "attention: head_dim must be 64 (d=%d, H=%d)", d, H);
-    WM_REQUIRE(S_pad % 64 == 0 && S_pad >= S, WM_ERR_INVALID, "attention: bad S_pad");
-    WmProfScope ps(&ctx->prof, "enc_attention", ctx->stream);
+template <bool SM, int ABL, int OCC>
+float run(const bf16_t *qk, const bf16_t *vt, bf16_t *att, int B, int H, int S, int S_pad, int d, int iters) {
     const int n_q = (S + 127) / 128, n_bh = B * H;
     const int grid = (n_bh + 7) / 8 * 8 * n_q;
-    if (g_wm_tuning.enc_attn_valu_sum)
-        enc_attn_kernel<false><<<grid, 256, 0, ctx->stream>>>(qk, vt, att, H, S, S_pad, d, n_q, n_bh);
-    else
-        enc_attn_kernel<true><<<grid, 256, 0, ctx->stream>>>(qk, vt, att, H, S, S_pad, d, n_q, n_bh);
-    WM_HIP(hipGetLastError());
-    return WM_OK;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) enc_attn_kernel<SM, ABL, OCC><<<grid, 256>>>(qk, vt, att, H, S, S_pad, d, n_q, n_bh);
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) enc_attn_kernel<SM, ABL, OCC><<<grid, 256>>>(qk, vt, att, H, S, S_pad, d, n_q, n_bh);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e3f / iters;
+}
+int main(int argc, char **argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 8, H = 20, S = 1500, S_pad = 1536, d = 1280;
+    const size_t M = (size_t)B * S;
+    std::vector<bf16_t> hq((M + 64) * 2 * d), hv((size_t)B * H * 64 * S_pad);
+    unsigned x = 1;
+    auto rnd = [&]() { x = x * 1664525u + 1013904223u; return ((float)(x >> 8) / 16777216.0f - 0.5f) * 2.0f; };
+    auto bf = [](float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); };
+    for (auto &v : hq) v = bf(rnd() * 1.5f);
+    for (auto &v : hv) v = bf(rnd());
+    bf16_t *qk, *vt, *att;
+    hipMalloc(&qk, hq.size() * 2); hipMalloc(&vt, hv.size() * 2); hipMalloc(&att, M * d * 2);
+    hipMemcpy(qk, hq.data(), hq.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(vt, hv.data(), hv.size() * 2, hipMemcpyHostToDevice);
+    const double gf = 4.0 * B * S * (double)S * d / 1e9;
+#define RUN(SM, ABL, OCC, what) { float us = run<SM, ABL, OCC>(qk, vt, att, B, H, S, S_pad, d, 20); \
+        printf("%-58s %8.1f us  (%5.0f TF/s-equivalent)\n", what, us, gf / us * 1e-3 * 1e3); }
+    RUN(true, 0, 3, "full kernel, ones-MFMA row sum, 3 waves/SIMD");
+    RUN(false, 0, 3, "full kernel, VALU row sum, 3 waves/SIMD");
+    RUN(false, 0, 2, "full kernel, VALU row sum, 2 waves/SIMD");
+    RUN(false, 32, 3, "never rescale after the first tile");
+    RUN(false, 2, 3, "no exp (cvt only)");
+    RUN(false, 1, 3, "no QK^T MFMAs");
+    RUN(false, 4, 3, "no PV MFMAs");
+    RUN(false, 5, 3, "no MFMAs at all");
+    RUN(false, 8, 3, "no global->LDS staging (same tile re-read)");
+    RUN(false, 16, 3, "no barrier (racy)");
+    RUN(false, 24, 3, "no staging, no barrier");
+    RUN(false, 26, 3, "no staging, no barrier, no exp");
+    RUN(false, 31, 3, "no staging / barrier / exp / MFMAs (LDS reads + max + cvt)");
+    return 0;
 }

@@ -7,6 +7,11 @@ B = pkg.binding
 dims = B.MODEL_DIMS["large-v2"]
 ctx = B.Context(dims, debug=True); ctx.init_synthetic(1); ctx.finalize()
 ctx.lib.wmdbg_set_gemm_tile.argtypes = [ctypes.c_int]
+ctx.lib.wmdbg_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
+for kv in [a for a in sys.argv[1:] if "=" in a]:
+    k, v = kv.split("=")
+    assert ctx.lib.wmdbg_set_tuning(k.encode(), int(v)) == 0
+sys.argv = [a for a in sys.argv if "=" not in a]
 mel = np.random.default_rng(0).standard_normal((8, 80, 3000)).astype(np.float32) * 0.3
 d_mel = ctx.to_device(mel); d_xa = ctx.dev_malloc(8 * 1500 * 1280 * 4)
 out = {}
