@@ -144,7 +144,7 @@ extern "C" int wmdbg_enc_attention(wm_ctx *ctx, const float *q, const float *k, 
     for (int b = 0; b < B; ++b)
         for (int s = 0; s < S; ++s)
             for (int j = 0; j < d; ++j)
-                vt[((size_t)(b * H + j / 64) * 64 + j % 64) * S_pad + s] = bf(v[((size_t)b * S + s) * d + j]);
+                vt[((size_t)(b * H + j / 64) * 64 + j % 64) * S_pad + wm_att_vt_pos((unsigned)s)] = bf(v[((size_t)b * S + s) * d + j]);
     void *dqk, *dvt, *datt;
     hipStream_t st = ctx->stream;
     WM_TRY(up(&dqk, qk.data(), qk.size() * 2, st));

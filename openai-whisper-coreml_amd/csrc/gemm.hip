@@ -106,7 +106,7 @@ __device__ __forceinline__ void store_tile(const GemmDev &p, const f32x4 (&acc)[
         if (EPI == EPI_QKV_ENC) {
             // 4 consecutive frames of one chunk (seq % 4 == 0 is not required: rows are checked) -> one 8-B store
             const unsigned b = (unsigned)mb / seq, sq = (unsigned)mb - b * seq;
-            const long roff = (long)b * p.n_head * 64 * p.seq_pad + sq;
+            const long roff = (long)b * p.n_head * 64 * p.seq_pad + wm_att_vt_pos(sq);   // sq % 4 == 0: the 4 frames stay together
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 if (!vpart[j] || ncol0 + j * 16 >= p.N) continue;
@@ -121,7 +121,7 @@ __device__ __forceinline__ void store_tile(const GemmDev &p, const f32x4 (&acc)[
                         const unsigned m = (unsigned)mb + r;
                         if ((int)m >= p.M) continue;
                         const unsigned b2 = m / seq, s2 = m - b2 * seq;
-                        p.vt[(long)b2 * p.n_head * 64 * p.seq_pad + s2 + coff[j]] = f2bf(c[r] + bv[j]);
+                        p.vt[(long)b2 * p.n_head * 64 * p.seq_pad + wm_att_vt_pos(s2) + coff[j]] = f2bf(c[r] + bv[j]);
                     }
                 }
             }

@@ -242,6 +242,10 @@ enum GemmEpi {
 // The encoder's queries are stored PRE-SCALED by hd^-1/2 * log2(e) (hd = 64): one f32 multiply in the QKV epilogue before
 // its single bf16 rounding, so that the attention kernel's score accumulators are exponents of 2 already (enc_kernels.hip).
 #define WM_ENC_QSCALE (0.125f * 1.44269504088896340736f)
+// Key position s of a chunk -> its column in the encoder's V^T buffer [b][h][e][seq_pad]: the two middle 4-key groups of
+// every 16 keys are swapped, so that the 8 keys one lane of the attention kernel multiplies per MFMA k-step are 16
+// contiguous bytes (enc_kernels.hip).
+__host__ __device__ static inline unsigned wm_att_vt_pos(unsigned s) { return (s & ~12u) | ((s & 4u) << 1) | ((s & 8u) >> 1); }
 struct GemmArgs {
     const bf16_t *A;   // rows addressed as (m / a_rpb) * a_bstride + (m % a_rpb) * a_rstride
     long a_rpb, a_bstride, a_rstride;

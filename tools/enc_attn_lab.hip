@@ -1,7 +1,7 @@
 // enc_attn_lab.hip -- standalone ablation lab for the encoder attention kernel (tools/, not product): the kernel text of
 // csrc/enc_kernels.hip with pieces switched off by a template mask, timed at large-v2 geometry.  Results of an ablated
 // variant are WRONG by construction; only the times mean something.
-//   ABL bits: 1 no QK^T MFMAs, 2 no exp, 4 no PV MFMAs, 8 no global->LDS staging, 16 no barrier, 32 never rescale
+//   ABL bits: 1 no QK^T MFMAs, 2 no exp, 4 no PV MFMAs, 8 no LDS-DMA, 16 no barrier, 32 never rescale, 64 no ds_reads
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/enc_attn_lab.hip -o tools/build/enc_attn_lab
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -20,27 +20,43 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return (bf16_t)(u >> 16);
 }
 __device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
-constexpr int KS_STRIDE = 144;  // bytes per K row in LDS (128 + 16 pad): conflict-free b128
-constexpr int VS_STRIDE = 136;  // bytes per V^T row in LDS (128 + 8 pad): conflict-free b64
 constexpr float ATT_RESCALE_THR = 8.0f;   // log2 units: p <= 2^8 before the reference moves
+
+// K / V^T tiles in LDS (round 4, second half): a tile is 64 rows x 128 bytes (K: 64 keys x 64 dims; V^T: 64 dims x 64
+// keys) = 8 KiB, brought in by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane, no VGPR round trip, no ds_write) into
+// a ring of three {K, V^T} slots: the tile after next is requested at the top of every tile and has a whole tile of
+// compute to land (round 3 staged through registers and waited for its own loads at the end of the same tile: the lab
+// -- tools/enc_attn_lab.hip -- attributed 28 % of the kernel to that).  LDS-DMA writes a wave's 64 x 16 bytes lane-
+// linearly, so rows cannot be padded; bank conflicts are avoided by an XOR swizzle instead: rows are paired into 256-byte
+// super-rows (16 chunks of 16 bytes), chunk p of super-row sr lives at position p ^ (sr & 15).  The swizzle is applied to
+// the SOURCE address of each lane's DMA and again to the ds_read_b128 address (same involution) -- conflict-free for the
+// fragment reads (lane = row % 32, half = lane / 32 reads chunk 2 i + half).  Both operands are read with ds_read_b128:
+// V^T is stored in HBM with the two middle 4-key groups of every 16 keys swapped (att_vt_pos, written so by the QKV
+// epilogue), which makes the 8 keys a lane multiplies in one MFMA k-step -- {0-3, 8-11} or {4-7, 12-15} of the 16, the
+// order the score accumulators hold -- one contiguous 16-byte chunk.
+constexpr int ATT_TILE_BYTES = 64 * 128;             // one operand tile
+constexpr int ATT_SLOT_BYTES = 2 * ATT_TILE_BYTES;   // K + V^T
+constexpr int ATT_RING = 3;
+
+#define ATT_DSR(dst, addr, off) do { if (ABL & 64) { dst = qf[0]; } else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory"); } while (0)
 
 template <bool SUM_MFMA, int ABL, int OCC>
 __global__ __launch_bounds__(256, OCC) void enc_attn_kernel(const bf16_t *__restrict__ qk,
                                                           const bf16_t *__restrict__ vt,
                                                           bf16_t *__restrict__ att, int H, int S,
                                                           int S_pad, int d, int n_q, int n_bh) {
-    __shared__ __attribute__((aligned(16))) char ks[2][64 * KS_STRIDE];
-    __shared__ __attribute__((aligned(16))) char vs[2][64 * VS_STRIDE];
+    __shared__ __attribute__((aligned(1024))) char ring[ATT_RING * ATT_SLOT_BYTES];
     // XCD-aware workgroup map.  The n_q query blocks of one (chunk, head) pair all stream the same 384 KB of K / V^T;
     // dispatch places workgroup w on XCD w % 8 (observed, not guaranteed: a wrong guess only costs speed), and each XCD
     // has a private L2 -- so the pairs are dealt to the XCDs (pair % 8) and the n_q blocks of a pair are CONSECUTIVE
     // workgroups of that XCD: K / V^T is fetched from HBM once per pair instead of once per XCD that happens to hold one
     // of its query blocks (round 1, grid (n_q, pairs): 537 MB fetched per launch for 93 MB of Q + K + V^T).
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int bh = (j / n_q) * 8 + xcd, qblk = j % n_q;
+    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3;
+    const int bh = (j0 / n_q) * 8 + xcd, qblk = j0 % n_q;
     if (bh >= n_bh) return;  // workgroup-uniform (pair count padded to a multiple of 8)
     const int b = bh / H, h = bh % H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hf = lane >> 5;
     const int q = qblk * 128 + wave * 32 + ql;
     const int qc = q < S ? q : S - 1;
@@ -54,32 +70,40 @@ __global__ __launch_bounds__(256, OCC) void enc_attn_kernel(const bf16_t *__rest
         for (int s4 = 0; s4 < 4; ++s4) qf[s4] = *(const bf16x8 *)(qp + 16 * s4);
     }
 
-    // tile staging: 512 16-byte chunks per operand; thread handles chunks tid and tid+256.  Addresses are a wave-uniform
-    // base (SGPRs) + a 32-bit per-thread byte offset that advances by a constant per tile.
+    // ---- DMA sources.  Wave w issues two 1-KiB pieces per operand and tile: piece i covers super-rows (2 w + i) * 4 .. + 3;
+    // lane l lands at super-row sr = that + l / 16, position l % 16, and therefore fetches logical chunk p = (l % 16) ^
+    // (sr & 15) of the super-row: tile row 2 sr + p / 8, 16-byte chunk p % 8.
     const char *kbase = (const char *)(qk + (long)b * S * ld + d + h * 64);
     const char *vbase = (const char *)(vt + (long)(b * H + h) * 64 * S_pad);
-    const int row0 = tid >> 3, c8 = tid & 7, row1 = row0 + 32;
-    const unsigned kstep = (unsigned)(64 * ld * 2);            // bytes between consecutive 64-key tiles of K
-    unsigned ko0 = (unsigned)(row0 * ld * 2 + c8 * 16), ko1 = (unsigned)(row1 * ld * 2 + c8 * 16);
-    unsigned vo0 = (unsigned)(row0 * S_pad * 2 + c8 * 16), vo1 = (unsigned)(row1 * S_pad * 2 + c8 * 16);
-    uint4 kr0, kr1, vr0, vr1;
-#define ATT_GLOAD_NEXT()                                                    \
-    do {                                                                    \
-        ko0 += kstep; ko1 += kstep; vo0 += 128u; vo1 += 128u;               \
-        kr0 = *(const uint4 *)(kbase + ko0);                                \
-        kr1 = *(const uint4 *)(kbase + ko1);                                \
-        vr0 = *(const uint4 *)(vbase + vo0);                                \
-        vr1 = *(const uint4 *)(vbase + vo1);                                \
-    } while (0)
-#define ATT_LSTORE(buf)                                                                            \
-    do {                                                                                           \
-        *(uint4 *)(ks[buf] + row0 * KS_STRIDE + c8 * 16) = kr0;                                    \
-        *(uint4 *)(ks[buf] + row1 * KS_STRIDE + c8 * 16) = kr1;                                    \
-        *(uint2 *)(vs[buf] + row0 * VS_STRIDE + c8 * 16) = make_uint2(vr0.x, vr0.y);               \
-        *(uint2 *)(vs[buf] + row0 * VS_STRIDE + c8 * 16 + 8) = make_uint2(vr0.z, vr0.w);           \
-        *(uint2 *)(vs[buf] + row1 * VS_STRIDE + c8 * 16) = make_uint2(vr1.x, vr1.y);               \
-        *(uint2 *)(vs[buf] + row1 * VS_STRIDE + c8 * 16 + 8) = make_uint2(vr1.z, vr1.w);           \
-    } while (0)
+    unsigned ksrc[2], vsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int sr = (wave * 2 + i) * 4 + (lane >> 4);
+        const int pl = (lane & 15) ^ (sr & 15);
+        const int row = 2 * sr + (pl >> 3), chunk = pl & 7;
+        ksrc[i] = (unsigned)(row * ld * 2 + chunk * 16);
+        vsrc[i] = (unsigned)(row * S_pad * 2 + chunk * 16);
+    }
+    const unsigned kstep = (unsigned)(64 * ld * 2);   // bytes between consecutive 64-key tiles of K (V^T: 128)
+    auto issue = [&](int slot, unsigned kadv, unsigned vadv) {
+        char *dk = ring + slot * ATT_SLOT_BYTES + wave * 2048;   // wave-uniform; the hardware adds lane * 16
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kbase + (ksrc[i] + kadv)),
+                                             (__attribute__((address_space(3))) void *)(dk + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vbase + (vsrc[i] + vadv)),
+                                             (__attribute__((address_space(3))) void *)(dk + ATT_TILE_BYTES + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read addresses: row = blk * 32 + ql, chunk = 2 i + hf  ->  blk * 4096 + (ql / 2) * 256 + (x0 ^ (i << 5))
+    // with x0 = ((((ql & 1) << 3) | hf) ^ ((ql >> 1) & 15)) << 4: four lane constants, the block and the operand are
+    // immediates, the ring slot one add per tile.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)ring;
+    const unsigned x0 = (unsigned)(((((ql & 1) << 3) | hf) ^ ((ql >> 1) & 15)) << 4);
+    unsigned fa[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = lds0 + (unsigned)((ql >> 1) * 256) + (x0 ^ (unsigned)(i << 5));
 
     f32x16 oacc[2], lacc, cneg;
 #pragma unroll
@@ -89,38 +113,48 @@ __global__ __launch_bounds__(256, OCC) void enc_attn_kernel(const bf16_t *__rest
         lacc[r] = 0.f;
         cneg[r] = 0.f;
     }
-    float ref = 0.f;   // the running reference r (log2 units) of this lane's query; -r lives in cneg
+    float ref = 0.f;      // the running reference r (log2 units) of this lane's query; -r lives in cneg
     float lsum_v = 0.f;   // !SUM_MFMA: the row sum of this lane's half of the keys, f32 VALU adds
     bf16x8 ones;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
 
     const int ntiles = (S + 63) / 64;
-    kr0 = *(const uint4 *)(kbase + ko0);
-    kr1 = *(const uint4 *)(kbase + ko1);
-    vr0 = *(const uint4 *)(vbase + vo0);
-    vr1 = *(const uint4 *)(vbase + vo1);
-    ATT_LSTORE(0);
-    __syncthreads();
+    issue(0, 0u, 0u);
+    if (ntiles > 1) issue(1, kstep, 128u);
+    // the Q loads and tile 0 have landed once at most the 4 pieces of tile 1 are outstanding (vmcnt counts in order)
+    if (ntiles > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     // One 64-key tile.  FIRST: the reference is taken from this tile's maximum (unconditionally: l >= 1 from then on);
     // LAST: keys >= S masked (the only tile that can hold any).
     auto tile = [&](int j, auto first_tag, auto last_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr bool LAST = decltype(last_tag)::value;
-        const int buf = j & 1;
-        if (!LAST && !(ABL & 8)) ATT_GLOAD_NEXT();
+        const int slot = j % ATT_RING;
+        if (j + 2 < ntiles && !(ABL & 8)) issue((j + 2) % ATT_RING, (unsigned)(j + 2) * kstep, (unsigned)(j + 2) * 128u);
+        const unsigned so = (unsigned)(slot * ATT_SLOT_BYTES);
+        const unsigned a0 = fa[0] + so, a1 = fa[1] + so, a2 = fa[2] + so, a3 = fa[3] + so;
         // ---- S^T - r = K Q^T + (-r) : two 32-kv blocks, the reference enters as the C operand -----------
+        bf16x8 kf[2][4];
+        ATT_DSR(kf[0][0], a0, 0); ATT_DSR(kf[0][1], a1, 0); ATT_DSR(kf[0][2], a2, 0); ATT_DSR(kf[0][3], a3, 0);
+        ATT_DSR(kf[1][0], a0, 4096); ATT_DSR(kf[1][1], a1, 4096); ATT_DSR(kf[1][2], a2, 4096); ATT_DSR(kf[1][3], a3, 4096);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][0]), "+v"(kf[1][1]),
+                       "+v"(kf[1][2]), "+v"(kf[1][3])::"memory");
         f32x16 st[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const char *kp = ks[buf] + (kb * 32 + ql) * KS_STRIDE + hf * 16;
+        for (int s4 = 0; s4 < 4; ++s4)   // the two chains interleaved: no MFMA waits for the one just issued
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const bf16x8 kf = *(const bf16x8 *)(kp + s4 * 32);
-                if (!(ABL & 1)) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s4], s4 == 0 ? cneg : st[kb], 0, 0, 0);
-                else if (s4 == 0) { st[kb] = cneg; st[kb][0] += (float)kf[0]; }
-            }
-        }
+            for (int kb = 0; kb < 2; ++kb)
+                if (!(ABL & 1)) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][s4], qf[s4], s4 == 0 ? cneg : st[kb], 0, 0, 0);
+                else if (s4 == 0) { st[kb] = cneg; st[kb][0] += (float)kf[kb][0][0] + (float)kf[kb][1][0] + (float)kf[kb][2][0] + (float)kf[kb][3][0]; }
+        // V^T fragments of the tile, requested now: they land under the softmax
+        bf16x8 vf[2][4];   // [eb][kb * 2 + j2]
+        ATT_DSR(vf[0][0], a0, ATT_TILE_BYTES); ATT_DSR(vf[0][1], a1, ATT_TILE_BYTES);
+        ATT_DSR(vf[0][2], a2, ATT_TILE_BYTES); ATT_DSR(vf[0][3], a3, ATT_TILE_BYTES);
+        ATT_DSR(vf[1][0], a0, ATT_TILE_BYTES + 4096); ATT_DSR(vf[1][1], a1, ATT_TILE_BYTES + 4096);
+        ATT_DSR(vf[1][2], a2, ATT_TILE_BYTES + 4096); ATT_DSR(vf[1][3], a3, ATT_TILE_BYTES + 4096);
         if constexpr (LAST) {  // mask kv >= S
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -158,34 +192,39 @@ __global__ __launch_bounds__(256, OCC) void enc_attn_kernel(const bf16_t *__rest
             for (int r = 0; r < 16; ++r) cneg[r] = -ref;
         }
         // ---- P^T = exp2(S^T - r) -> bf16;  O^T += V^T P^T;  l += 1^T P^T -------------------------------
+        bf16x8 pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int j2 = 0; j2 < 2; ++j2) {
                 f32x8 p8;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) p8[i] = (ABL & 2) ? st[kb][8 * j2 + i] : __builtin_amdgcn_exp2f(st[kb][8 * j2 + i]);
-                const bf16x8 pf = __builtin_convertvector(p8, bf16x8);  // 4 x v_cvt_pk_bf16_f32
+                for (int i = 0; i < 8; ++i) p8[i] = (ABL & 2) ? st[kb][8 * j2 + i] * 0.001f : __builtin_amdgcn_exp2f(st[kb][8 * j2 + i]);
+                pf[kb][j2] = __builtin_convertvector(p8, bf16x8);  // 4 x v_cvt_pk_bf16_f32
                 if (!SUM_MFMA) lsum_v += ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
-                const int kvoff = kb * 32 + 16 * j2 + 4 * hf;  // + {0..3} and + 8 + {0..3}
-#pragma unroll
-                for (int eb = 0; eb < 2; ++eb) {
-                    const char *vp = vs[buf] + (eb * 32 + ql) * VS_STRIDE + kvoff * 2;
-                    const bf16x4 lo = *(const bf16x4 *)vp;
-                    const bf16x4 hi = *(const bf16x4 *)(vp + 16);
-                    bf16x8 vf;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        vf[i] = lo[i];
-                        vf[4 + i] = hi[i];
-                    }
-                    if (!(ABL & 4)) oacc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[eb], 0, 0, 0);
-                    else oacc[eb][0] += (float)vf[0] + (float)pf[0];
-                }
-                if (SUM_MFMA) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
             }
-        if (!LAST && !(ABL & 8)) ATT_LSTORE(buf ^ 1);
-        if (!(ABL & 16)) __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[0][2]), "+v"(vf[0][3]), "+v"(vf[1][0]), "+v"(vf[1][1]),
+                       "+v"(vf[1][2]), "+v"(vf[1][3])::"memory");
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+#pragma unroll
+                for (int eb = 0; eb < 2; ++eb)
+                    if (!(ABL & 4)) oacc[eb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[eb][kb * 2 + j2], pf[kb][j2], oacc[eb], 0, 0, 0);
+                    else oacc[eb][0] += (float)vf[eb][kb * 2 + j2][0] + (float)pf[kb][j2][0];
+                if (SUM_MFMA) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[kb][j2], lacc, 0, 0, 0);
+            }
+        // the NEXT tile must have landed (this wave's share: everything but the 4 pieces just issued), and every wave must
+        // be done reading this slot before the tile after next overwrites it
+        if (!LAST) {
+            if (!(ABL & 8)) {
+                if (j + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (!(ABL & 16)) __builtin_amdgcn_s_barrier();
+        }
     };
     if (ntiles == 1) {
         tile(0, std::true_type{}, std::true_type{});
@@ -209,7 +248,6 @@ __global__ __launch_bounds__(256, OCC) void enc_attn_kernel(const bf16_t *__rest
             }
     }
 }
-
 
 template <bool SM, int ABL, int OCC>
 float run(const bf16_t *qk, const bf16_t *vt, bf16_t *att, int B, int H, int S, int S_pad, int d, int iters) {
@@ -242,18 +280,19 @@ int main(int argc, char **argv) {
     const double gf = 4.0 * B * S * (double)S * d / 1e9;
 #define RUN(SM, ABL, OCC, what) { float us = run<SM, ABL, OCC>(qk, vt, att, B, H, S, S_pad, d, 20); \
         printf("%-58s %8.1f us  (%5.0f TF/s-equivalent)\n", what, us, gf / us * 1e-3 * 1e3); }
-    RUN(true, 0, 3, "full kernel, ones-MFMA row sum, 3 waves/SIMD");
-    RUN(false, 0, 3, "full kernel, VALU row sum, 3 waves/SIMD");
-    RUN(false, 0, 2, "full kernel, VALU row sum, 2 waves/SIMD");
-    RUN(false, 32, 3, "never rescale after the first tile");
-    RUN(false, 2, 3, "no exp (cvt only)");
-    RUN(false, 1, 3, "no QK^T MFMAs");
-    RUN(false, 4, 3, "no PV MFMAs");
-    RUN(false, 5, 3, "no MFMAs at all");
-    RUN(false, 8, 3, "no global->LDS staging (same tile re-read)");
-    RUN(false, 16, 3, "no barrier (racy)");
-    RUN(false, 24, 3, "no staging, no barrier");
-    RUN(false, 26, 3, "no staging, no barrier, no exp");
-    RUN(false, 31, 3, "no staging / barrier / exp / MFMAs (LDS reads + max + cvt)");
+    RUN(true, 32, 2, "full kernel (never rescale), ones-MFMA row sum, 2 waves/SIMD");
+    RUN(false, 32, 2, "full kernel (never rescale), VALU row sum, 2 waves/SIMD");
+    RUN(false, 0, 2, "full kernel, rescale as the data asks");
+    RUN(false, 32 + 2, 2, "no exp");
+    RUN(false, 32 + 1, 2, "no QK^T MFMAs");
+    RUN(false, 32 + 4, 2, "no PV MFMAs");
+    RUN(false, 32 + 5, 2, "no MFMAs at all");
+    RUN(false, 32 + 8, 2, "no LDS-DMA (slots never refilled)");
+    RUN(false, 32 + 16, 2, "no barrier (racy)");
+    RUN(false, 32 + 24, 2, "no DMA, no barrier");
+    RUN(false, 32 + 64, 2, "no ds_reads (fragments = constants)");
+    RUN(false, 32 + 64 + 24, 2, "no ds_reads, no DMA, no barrier (MFMA + softmax only)");
+    RUN(false, 32 + 64 + 24 + 2, 2, "... and no exp (MFMA + max + cvt)");
+    RUN(false, 32 + 64 + 24 + 5, 2, "no ds_reads / DMA / barrier / MFMA (softmax VALU only)");
     return 0;
 }
