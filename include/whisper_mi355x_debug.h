@@ -77,7 +77,7 @@ WM_API int wmdbg_set_precision(wm_ctx *ctx, int precision);
 
 /* Launch-shape experiment knobs (csrc/wm_internal.h, struct WmTuning), by name: "gemv_tn", "gemv_nblk", "gemv_no_ppw2",
  * "prefetch_max_b", "xattn_split_below", "xattn_wgs", "xattn_no_flat", "xattn_lds_pad", "xattn_splits", "gemm_tile",
- * "gemm_gm", "no_early_stop", "xattn_no_deep", "xattn_never_short", "logits_tn"; key "reset" restores the product's rules.  Process-wide.  The PRODUCT library has no such
+ * "gemm_gm", "no_early_stop", "xattn_no_deep", "xattn_never_short", "logits_tn", "enc_attn_mfma_sum"; key "reset" restores the product's rules.  Process-wide.  The PRODUCT library has no such
  * entry point and reads no environment variable for launch shapes (rounds 1-3 had WM_GEMV_*, WM_XATTN_*, WM_GEMM_*). */
 WM_API int wmdbg_set_tuning(const char *key, int value);
 

@@ -121,8 +121,8 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float *__restric
 //     (a separate 16-register tuple holding -r): the accumulator comes out as s - r in log2 units, p = exp2(acc);
 //   * r is a LAGGED maximum: it moves (and O, l are rescaled, and the C tuple rewritten) only when a score of the tile
 //     exceeds it by more than 2^8 -- on the first tile, and rarely afterwards; p <= 256 is exact enough in bf16 / f32;
-//   * the row sum l is a fifth accumulator fed by the SAME bf16 P^T fragments against an all-ones A operand (4 MFMAs per
-//     tile instead of 16 packed adds + a cross-lane exchange): l sums exactly the probabilities O was built from.
+//   * (measured, not adopted: the row sum l as a fifth accumulator fed by the same bf16 P^T fragments against an all-ones
+//     A operand -- 4 MFMAs per tile instead of 16 packed adds; SUM_MFMA, debug knob enc_attn_mfma_sum.)
 constexpr float ATT_RESCALE_THR = 8.0f;   // log2 units: p <= 2^8 before the reference moves
 
 // K / V^T tiles in LDS (round 4, second half): a tile is 64 rows x 128 bytes (K: 64 keys x 64 dims; V^T: 64 dims x 64
@@ -388,10 +388,12 @@ int wm_enc_attention(wm_ctx *ctx, const bf16_t *qk, const bf16_t *vt, bf16_t *at
     WmProfScope ps(&ctx->prof, "enc_attention", ctx->stream);
     const int n_q = (S + 127) / 128, n_bh = B * H;
     const int grid = (n_bh + 7) / 8 * 8 * n_q;
-    if (g_wm_tuning.enc_attn_valu_sum)
-        enc_attn_kernel<false><<<grid, 256, 0, ctx->stream>>>(qk, vt, att, H, S, S_pad, d, n_q, n_bh);
-    else
+    // row sums as f32 VALU adds; the ones-operand MFMA variant (4 more MFMAs, 16 fewer packed adds per tile) measured
+    // 132 vs 119 us per layer at 8 chunks inside the model and is kept behind the debug knob only
+    if (g_wm_tuning.enc_attn_mfma_sum)
         enc_attn_kernel<true><<<grid, 256, 0, ctx->stream>>>(qk, vt, att, H, S, S_pad, d, n_q, n_bh);
+    else
+        enc_attn_kernel<false><<<grid, 256, 0, ctx->stream>>>(qk, vt, att, H, S, S_pad, d, n_q, n_bh);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

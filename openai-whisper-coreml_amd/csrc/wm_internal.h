@@ -170,7 +170,7 @@ struct WmTuning {
     int gemm_gm = 4;              // grouped tile order of the encoder GEMM
     int no_early_stop = 0;        // 1: decode every position and truncate on the host (the round-2 behaviour)
     int logits_tn = 0;            // 1 / 2: tiles per workgroup of the logits product at <= 16 rows (product: 4)
-    int enc_attn_valu_sum = 0;    // 1: encoder attention row sums as f32 VALU adds instead of the ones-operand MFMA
+    int enc_attn_mfma_sum = 0;    // 1: encoder attention row sums by a ones-operand MFMA instead of f32 VALU adds
     int xattn_never_short = 0;    // 1: persistent cross-attention workgroups also when the chip is shared (rounds 2-3)
     int xattn_no_deep = 0;        // 1: the flat (few-pair) cross-attention walks its blocks one round trip at a time
 };
