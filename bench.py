@@ -605,7 +605,10 @@ def main():
                                          # every decode family's mean launch duration (event bias subtracted) in this pass
                                          "families_avg_us": {k_: max(v_[0] / v_[1] * 1e3 - ev_over, 0.0)
                                                              for k_, v_ in sorted(fam_all.items()) if k_.startswith(("dec_", "argmax")) and v_[1]},
-                                         "note": "same plan, %d groups in flight, eager event-bracketed launches on every lane" % S}
+                                         "note": "same plan, %d groups in flight, eager event-bracketed launches on every lane; a "
+                                                 "launch's duration here includes the time its (short-lived) workgroups wait for "
+                                                 "CUs that other groups' kernels hold, so this frac understates the stream's own "
+                                                 "rate -- the decode stage's aggregate rate is stage_roofline.decode" % S}
             if kind == "hbm":
                 ach = work / avg_s / 1e9
                 roof = dict(common, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
