@@ -227,22 +227,23 @@ def smoke_check(pkg):
     from oracle import logmel_np
     w = importlib.import_module("openai_whisper_coreml_amd.weights")
     dims = dict(TINY_DIMS)
-    sd_np = w.synthetic_state_dict(dims, seed=1)
+    sd_np = w.synthetic_state_dict(dims, seed=1, matrix_gain=4.0)   # the `lively` recipe: tokens depend on audio and history
     sd = to_torch(sd_np)
     ctx = pkg.binding.Context(dims)
     ctx.load_state_dict(sd_np)
     ctx.finalize()
-    pcm = logmel_np.synth_chunk(0)[None, :]
+    n = np.arange(480000, dtype=np.float64)
+    pcm = (0.3 * np.sin(2 * np.pi * 570 * n / 16000) * (0.5 + 0.5 * np.sin(2 * np.pi * 0.4 * n / 16000))).astype(np.float32)[None, :]
     mel = ctx.logmel(pcm, out_dtype=np.float32)
     xa_gpu = ctx.encode_mel(mel)
     xa_ref = encode(sd, dims, mel).numpy()
     e = rel_l2(xa_gpu, xa_ref)
     assert e < 3e-2, "encoder rel-L2 %g" % e
     prompt = [1, 2]
-    toks, lens = ctx.transcribe_greedy(pcm, prompt, 6, eot=-1)
-    ref_t, _, ref_logits = greedy(sd, dims, xa_gpu, prompt, 6)
+    toks, lens = ctx.transcribe_greedy(pcm, prompt, 12, eot=-1)
+    ref_t, _, ref_logits = greedy(sd, dims, xa_gpu, prompt, 12)
     # the GPU-chosen token must be (near-)maximal under the fp32 oracle's logits
-    for s in range(6):
+    for s in range(12):
         if toks[0, s] != ref_t[0, s]:
             gap = ref_logits[0, s].max() - ref_logits[0, s, toks[0, s]]
             assert gap < 0.05, "step %d: token %d vs %d, oracle logit gap %g" % (s, toks[0, s], ref_t[0, s], gap)
