@@ -48,6 +48,21 @@ def test_bench_distributed_branch_runs_at_world_size_one():
     assert roof["in_situ"]["lanes"] == 3 and roof["in_situ"]["avg_us"] >= 0.8 * roof["avg_us"]
 
 
+def test_bench_total_chunks_is_the_strong_scaling_job():
+    """BASELINE.json configs[4] as a command: `--total-chunks N` block-partitions ONE job of N chunks over the ranks
+    (sharding.partition) -- here N = 6 on one rank, tiny.en: scaling "strong", value = 30 N steps / time, one decode group
+    of the rank's 6 chunks per step."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--model", "tiny.en", "--total-chunks", "6",
+                        "--steps", "2", "--warmup", "1", "--inflight", "1", "--fuse", "1", "--new-tokens", "16",
+                        "--no-cpu-baseline", "--no-early-stop"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["config"]["total_chunks"] == 6 and line["config"]["chunks_per_gpu"] == 6
+    assert line["config"]["decode_groups"] == [1, 1] and line["token_rows"] == 12
+    assert abs(line["value"] - 30.0 * 6 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    assert line["tokens_consistent_across_groups"] is True
+
+
 def test_two_all_gpu_hosts_share_one_device(pkg):
     """Two dlopen-only hosts (host/multi_main.cpp: wm_multi_create -> ncclCommInitAll -> all-gather), started together on
     the same GPU: RCCL initialisation and the lazily bound library must not depend on being alone on the device."""
