@@ -1525,3 +1525,45 @@ def test_flat_cross_attention_launch_shapes_are_bitwise_equal(pkg):
     lg1, lg3, lg16, gen, solo = outs[0]
     assert np.array_equal(lg1[0], lg16[0]) and np.array_equal(lg3, lg16[:3])
     assert np.array_equal(solo[0], gen[1]) and len({r.tobytes() for r in gen}) == 3
+
+
+def _hip_free_bytes():
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    return free.value
+
+
+def test_context_lifecycle_returns_device_memory(pkg):
+    """wm_create ... wm_destroy in a long-lived host process (the reference keeps ONE `Whisper` for the app's lifetime,
+    ContentView.swift:11,15 -- a server creates and drops many): every path that allocates lazily is driven -- encoder
+    work space, cross-K/V, lanes with their captured graphs (both cross-attention variants), early stop, budgets, a clone,
+    the stateless logits call -- and after wm_destroy the device's free memory is back where it was.  The first cycle is
+    the warm-up (HIP's own module / graph pools fill once); cycles 2..4 must not lose anything."""
+    dims = dict(R.TINY_DIMS)
+    pcm = tones(5)
+
+    def cycle():
+        ctx = pkg.binding.Context(dims)
+        ctx.init_synthetic(3, matrix_gain=4.0)
+        ctx.finalize()
+        ctx.set_lanes(3)
+        t0, l0 = ctx.transcribe_greedy(pcm, [10, 21], 12)
+        ctx.set_token_budgets([3, 12, 7, 12, 5])
+        t1, l1 = ctx.transcribe_greedy(pcm, [10, 21], 12, eot=int(t0[0, 4]))
+        c = ctx.clone()
+        t2, _ = c.transcribe_greedy(pcm[:2], [10, 21], 6)
+        xa = ctx.encode_mel(ctx.logmel(pcm[:1]))
+        ctx.decode_logits(np.array([[10, 21, 5]], np.int32), xa)
+        c.close()
+        ctx.close()
+        return t0, t2
+
+    first = cycle()
+    base = _hip_free_bytes()
+    for i in range(3):
+        again = cycle()
+        assert np.array_equal(again[0], first[0]) and np.array_equal(again[1], first[1])
+        lost = base - _hip_free_bytes()
+        assert lost <= (8 << 20), "cycle %d: %.1f MiB of device memory not returned" % (i + 2, lost / 2**20)
