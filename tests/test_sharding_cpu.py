@@ -93,6 +93,9 @@ def test_wav_reader_roundtrip(tmp_path):
 def test_plan_groups_is_deterministic_and_balanced():
     assert S.plan_groups(20, 12, 3) == [7, 7, 6]            # the driver's `--steps 20` with 3 lanes
     assert S.plan_groups(72, 12, 3) == [12] * 6
+    assert S.plan_groups(72, 16, 3) == [12] * 6             # whole rounds of the lanes, not 15/15/14/14/14
+    assert S.plan_groups(100, 16, 3) == [12] + [11] * 8
+    assert S.plan_groups(4, 1, 3) == [1] * 4                # ... unless there are not enough steps for that
     assert S.plan_groups(5, 12, 3) == [2, 2, 1]
     assert S.plan_groups(1, 12, 3) == [1]
     assert S.plan_groups(0, 12, 3) == []
