@@ -751,15 +751,12 @@ __global__ __launch_bounds__(64) void dec_attn_combine_kernel(const float *__res
 }
 
 // ------------------------------------------------------------------ arg-max -> next token
-// One workgroup of 16 waves closes a decode step for 16 sequences.  The launch sits on the critical path of every
-// position (it is 10 % of a tiny.en position), so each of its phases is ONE memory round trip:
-//   1. all 1024 threads fetch the per-tile packed maxima of the workgroup's rows together (8 rows x 4 keys per thread in
-//      flight; a maximum does not care who loaded what), wave shuffles + a [wave][row] LDS table finish the reduction;
-//   2. wave b closes row b: timestamp decision, early-stop flags, the token into the sequence buffer at position pos+1
-//      unless that position belongs to the prompt;
-//   3. the SAME launch embeds the tokens of position pos+1 (token + positional embedding, held in registers for the
-//      mean-centred bf16 copy, plus the LayerNorm partial statistics the next layer-0 GEMV expects) and advances the
-//      device-side position -- so a step has no separate embedding launch and *pos_ptr has exactly one writer.
+// ONE workgroup of 16 waves closes a decode step: wave b reduces the per-tile packed maxima of
+// sequence b (all loads in flight at once), the chosen token goes into the sequence buffer at
+// position pos+1 unless that position belongs to the prompt, then the SAME launch embeds the
+// tokens of position pos+1 (token + positional embedding, plus the LayerNorm partial statistics
+// the next layer-0 GEMV expects) and advances the device-side position -- so a step has no
+// separate embedding launch and *pos_ptr has exactly one writer.
 __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long long *__restrict__ tilemax,
                                                              int n_tiles, int B, int *__restrict__ seq,
                                                              int *__restrict__ pos_ptr, int n_prompt,
@@ -770,53 +767,26 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
                                                              float *__restrict__ stats_out, WmTsDev ts,
                                                              int *__restrict__ arrive, int fallback_tok,
                                                              float *__restrict__ mean_buf, WmStopDev stop) {
-    __shared__ unsigned long long key_s[16][16];   // [wave][row of the workgroup]
     __shared__ int tok_s[16];
     __shared__ int is_last_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pos = pos_ptr ? *pos_ptr : 0;
-    const int bw = blockIdx.x * 16;  // this workgroup's rows
-    const int nrow = B - bw < 16 ? B - bw : 16;
-    for (int r0 = 0; r0 < nrow; r0 += 8) {   // 8 rows x 4 keys per thread per trip: one trip up to 8 rows and 4096 tiles
-        unsigned long long best[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) best[r] = 0ull;
-        for (int t0 = threadIdx.x; t0 < n_tiles; t0 += 1024 * 4) {
-            unsigned long long k[8][4];
-            unsigned tt[4];   // byte offsets (32-bit: a uniform row base + one offset register per key in flight)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) tt[u] = 8u * (unsigned)(t0 + 1024 * u < n_tiles ? t0 + 1024 * u : t0);  // clamped: duplicates do not change a max
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                // rows past the workgroup's last are clamped too (a uniform base address, no branch around the loads)
-                const char *row = (const char *)(tilemax + (long)(bw + (r0 + r < nrow ? r0 + r : nrow - 1)) * n_tiles);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) k[r][u] = *(const unsigned long long *)(row + tt[u]);
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) best[r] = k[r][u] > best[r] ? k[r][u] : best[r];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            if (r0 + r < nrow) {
-                unsigned long long key = best[r];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const unsigned long long ok = __shfl_xor(key, o);
-                    key = ok > key ? ok : key;
-                }
-                if (lane == 0) key_s[wave][r0 + r] = key;
-            }
-        }
-    }
-    __syncthreads();
+    const int bw = blockIdx.x * 16;  // this workgroup's rows: one per wave
     for (int b = bw + wave; b < B && b < bw + 16; b += 16) {  // wave-uniform, at most one trip
-        unsigned long long key = key_s[lane & 15][b - bw];
+        const unsigned long long *row = tilemax + (long)b * n_tiles;
+        unsigned long long key = 0ull;
+        for (int t0 = lane; t0 < n_tiles; t0 += 64 * 8) {
+            unsigned long long k[8];
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + 64 * u;
+                k[u] = row[t < n_tiles ? t : t0];  // clamped: duplicates do not change a max
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) key = k[u] > key ? k[u] : key;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
             const unsigned long long ok = __shfl_xor(key, o);
             key = ok > key ? ok : key;
         }
@@ -896,46 +866,22 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
     if (x && pos + 1 < n_ctx) {
         for (int b = bw + wave; b < B && b < bw + 16; b += 16) {
             const long tok = tok_s[b - bw];
-            constexpr int VJ = WM_MAX_STATE / 64;   // the row stays in registers between the sums and the bf16 copy
-            float v[VJ];
-            bf16_t e[VJ];
-            // element lane + 64 i of a WL_TILED row sits 1024 i elements after element `lane` (wm_tiled_offset: two
-            // k-steps of 512 elements per 64 columns); 32-bit offsets from uniform bases keep 2 x VJ loads in flight
-            const bf16_t *erow = emb + wm_tiled_offset((size_t)tok, 0, (size_t)d);
-            const unsigned eoff = (unsigned)wm_tiled_offset(0, (size_t)lane, (size_t)d);
-            const float *prow = pemb + (long)(pos + 1) * d;
-#pragma unroll
-            for (int i = 0; i < VJ; ++i) {
-                e[i] = 0;
-                v[i] = 0.f;
-                if (lane + 64 * i < d) {
-                    e[i] = erow[eoff + 1024u * i];
-                    v[i] = prow[(unsigned)lane + 64u * i];
-                }
-            }
             float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < VJ; ++i) {
-                const int j = lane + 64 * i;
-                if (j < d) {
-                    v[i] = bf2f(e[i]) + v[i];
-                    (x + (long)b * d)[(unsigned)j] = v[i];
-                    s1 += v[i];
-                    s2 += v[i] * v[i];
-                }
+            for (int j = lane; j < d; j += 64) {
+                const float v = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)(pos + 1) * d + j];
+                x[(long)b * d + j] = v;
+                s1 += v;
+                s2 += v * v;
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 s1 += __shfl_xor(s1, o);
                 s2 += __shfl_xor(s2, o);
             }
-            {   // bf16 copy, mean-centred (see DecGemvDev::mean_in)
+            {   // bf16 copy, mean-centred (see DecGemvDev::mean_in); each lane re-reads the elements it just wrote
                 const float mean = s1 / (float)d;
-#pragma unroll
-                for (int i = 0; i < VJ; ++i) {
-                    const int j = lane + 64 * i;
-                    if (j < d) (xb + wm_tiled_offset((size_t)b, 0, (size_t)d))[eoff + 1024u * i] = f2bf(v[i] - mean);
-                }
+                for (int j = lane; j < d; j += 64)
+                    xb[wm_tiled_offset((size_t)b, (size_t)j, (size_t)d)] = f2bf(x[(long)b * d + j] - mean);
                 if (lane == 0 && mean_buf) mean_buf[b] = mean;
             }
             if (stats_out) {  // one part (index 0) carries the row; the other d/16 - 1 parts the consumers sum are zero
@@ -1358,7 +1304,6 @@ int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles,
     const int grid = arrive ? (B + 15) / 16 : 1;
     WM_REQUIRE(grid == 1 || B <= 16 * grid, WM_ERR_INVALID, "argmax_embed: bad grid");
     WM_REQUIRE(arrive || B <= 16, WM_ERR_INVALID, "argmax_embed: more than 16 rows need the arrival counter");
-    WM_REQUIRE(d <= WM_MAX_STATE, WM_ERR_INVALID, "argmax_embed: model width %d above %d", d, WM_MAX_STATE);
     argmax_embed_kernel<<<grid, 1024, 0, ctx->stream>>>(tilemax, n_tiles, B, seq, pos_ptr, n_prompt, result, arg_first,
                                                         emb, pemb, d, n_ctx, x, xb, stats_out, t, arrive, fallback_tok,
                                                         mean_buf, sp);

@@ -160,7 +160,7 @@ int wm_model_create(wm_ctx *ctx, const wm_dims *dims) {
     WM_REQUIRE(D.n_mels == 80 || D.n_mels == 128, WM_ERR_INVALID, "n_mels must be 80 or 128");
     WM_REQUIRE(D.n_audio_ctx == 1500, WM_ERR_INVALID, "n_audio_ctx must be 1500 (30 s chunks)");
     WM_REQUIRE(D.n_audio_state == D.n_text_state, WM_ERR_INVALID, "audio/text widths must match");
-    WM_REQUIRE(D.n_audio_state % 64 == 0 && D.n_audio_state <= WM_MAX_STATE && D.n_audio_state >= 64,
+    WM_REQUIRE(D.n_audio_state % 64 == 0 && D.n_audio_state <= 1280 && D.n_audio_state >= 64,
                WM_ERR_INVALID, "model width must be a multiple of 64 in [64, 1280]");
     WM_REQUIRE(D.n_audio_head * 64 == D.n_audio_state && D.n_text_head * 64 == D.n_text_state,
                WM_ERR_INVALID, "head_dim must be 64 (Whisper uses 64 at every size)");

@@ -271,7 +271,6 @@ int wm_enc_attention(wm_ctx *ctx, const bf16_t *qk, const bf16_t *vt, bf16_t *at
                      int S, int S_pad, int d);
 
 // dec_kernels.hip
-constexpr int WM_MAX_STATE = 1280;  // widest model (large): per-lane register rows of d / 64 elements are sized by it
 constexpr int WM_DEC_MAXB = 128;  // decode group: up to eight batch blocks of 16 rows (the MFMA M dimension)
 constexpr int WM_NLIVE_RING = 16;  // pinned host slots for the per-burst live-row counts (early stop)
 constexpr int WM_MAXSPLIT = 8;  // stream partials of a (sequence, head) pair of the cross-attention (small batches)
