@@ -14,9 +14,10 @@ is reported next to the pipelined throughput.  Everything runs through the C ABI
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--model large-v2] [--batch 8]
 
-N > 1: launched by torch.distributed.run, one rank per GPU; each rank owns its own chunks
-(weak scaling, no data-path collective) and the token streams are all-gathered over RCCL
-inside the timed region.  Prints ONE JSON line on rank 0.
+N > 1: one rank per GPU -- started by torch.distributed.run (the driver), or by bench.py itself when `--gpus N` is given
+without a launcher (it re-executes under torch.distributed.run); a launcher whose WORLD_SIZE differs from --gpus is an
+error.  Each rank owns its own chunks (weak scaling, no data-path collective) and the token streams are all-gathered over
+RCCL inside the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes
@@ -132,15 +133,24 @@ def other_configs(B, main_model, pcm16, max_new=224):
     Same weights recipe, same fixed-length greedy decode; every entry: audio-s/s of the call, its stage split (HIP events
     inside the library) and the stage rooflines."""
     out = {}
-    cases = [("tiny.en_b1_latency", "tiny.en", 1, 3), ("base_b32_one_group", "base", 32, 2),
-             ("large-v3_15_chunks_one_group", "large-v3", 15, 2)]
-    for key, model, nb, reps in cases:
+    # (key, model, chunks, repetitions, lanes): lanes 1 = ONE decode group on one lane; lanes 0 = the product's own policy
+    # (wm_transcribe_greedy splits the call into decode groups over $WM_LANES weight-sharing lanes: 15 chunks -> 8 + 7)
+    cases = [("tiny.en_b1_latency", "tiny.en", 1, 3, 1), ("base_b32_one_group", "base", 32, 2, 1),
+             ("large-v3_15_chunks_one_group", "large-v3", 15, 2, 1), ("large-v3_15_chunks_product_lanes", "large-v3", 15, 2, 0)]
+    ctx_cache = {}
+    for key, model, nb, reps, lanes in cases:
         try:
             dims = B.MODEL_DIMS[model]
-            c = B.Context(dims)
-            c.init_synthetic(20240928, matrix_gain=4.0)
-            c.finalize()
-            c.set_lanes(1)
+            c = ctx_cache.get(model)
+            if c is None:
+                for o in ctx_cache.values():
+                    o.close()
+                ctx_cache.clear()
+                c = B.Context(dims)
+                c.init_synthetic(20240928, matrix_gain=4.0)
+                c.finalize()
+                ctx_cache[model] = c
+            c.set_lanes(lanes)
             prompt = [50258, 50259, 50359, 50363] if dims["n_vocab"] >= 51865 else [50257, 50362]
             dp = c.to_device(pcm16[np.arange(nb) % len(pcm16)])
             best, stage = None, None
@@ -151,18 +161,109 @@ def other_configs(B, main_model, pcm16, max_new=224):
                 if i > 0 and (best is None or dt < best):
                     best, stage = dt, np.array(c.last_stage_ms(), dtype=np.float64) / 1e3
             out[key] = {"model": model, "chunks": nb, "value": 30.0 * nb / best, "unit": "audio-sec/s",
-                        "ms_per_step": best * 1e3, "decoder_tok_per_s": nb * max_new / max(stage[2], 1e-9),
-                        "decoder_ms_per_position": stage[2] * 1e3 / (len(prompt) + max_new - 1),
-                        "stage_ms": {"frontend": stage[0] * 1e3, "encoder_xkv": stage[1] * 1e3, "decode": stage[2] * 1e3},
-                        "stage_roofline": stage_rooflines(dims, nb, len(prompt), max_new, 1.0, stage),
+                        "ms_per_step": best * 1e3,
                         "step_roofline": step_roofline(dims, nb, len(prompt), max_new, 1.0, best),
                         "distinct_token_rows": len({r.tobytes() for r in toks}),
-                        "timing": "min of %d calls after one warm-up call, one decode group on one lane" % reps}
+                        "timing": "min of %d calls after one warm-up call, %s" % (
+                            reps, "one decode group on one lane" if lanes == 1 else
+                            "the product's own group / lane policy (wm_transcribe_greedy default)")}
+            if lanes == 1:   # per-stage figures only mean something for ONE group (lanes overlap their stages)
+                out[key].update({
+                    "decode_stage_tok_per_s": nb * max_new / max(stage[2], 1e-9),
+                    "decoder_ms_per_position": stage[2] * 1e3 / (len(prompt) + max_new - 1),
+                    "stage_ms": {"frontend": stage[0] * 1e3, "encoder_xkv": stage[1] * 1e3, "decode": stage[2] * 1e3},
+                    "stage_roofline": stage_rooflines(dims, nb, len(prompt), max_new, 1.0, stage)})
+            else:
+                out[key]["tokens_equal_one_group_run"] = bool(np.array_equal(toks, out.get("large-v3_15_chunks_one_group_tokens", toks)))
+            if key == "large-v3_15_chunks_one_group":
+                out["large-v3_15_chunks_one_group_tokens"] = toks
             c.dev_free(dp)
-            c.close()
         except Exception as e:   # never take the headline down
             out[key] = {"model": model, "chunks": nb, "value": None, "error": repr(e)}
+    out.pop("large-v3_15_chunks_one_group_tokens", None)
+    for o in ctx_cache.values():
+        o.close()
+    for name, fn in (("small_lid_reference_flow", reference_flow_small), ("frontend_reference_abi", frontend_alone)):
+        try:
+            out[name] = fn(B, pcm16)
+        except Exception as e:
+            out[name] = {"value": None, "error": repr(e)}
     return out
+
+
+def reference_flow_small(B, pcm16):
+    """The ONLY flow the reference itself runs (ContentView.swift:56-63, Whisper.swift:23-40): Whisper-small, ONE 30 s chunk
+    as 480 000 host doubles -> generate_spectrogram at the reference's f64 ABI (host buffers: the PCIe copies are in the
+    time) -> f64 -> f32 -> encoder -> ONE decoder step on <|startoftranscript|> -> arg-max over the 99 language ids.
+    Wall ms of binding.Whisper.encode + .decode (the Swift surface's names), min of 5 after one warm-up call; beside it the
+    CPU oracle's time for the same flow on this box's host cores (C front end on 1 thread, torch fp32 model)."""
+    import ctypes as C
+    w = B.Whisper("small", synthetic_seed=20240928)
+    x = pcm16[1].astype(np.float64) / 32768.0
+    best, parts = None, None
+    lang = None
+    for i in range(6):
+        t0 = time.perf_counter()
+        feats = w.encode(x)
+        t1 = time.perf_counter()
+        lang = w.decode(feats)
+        t2 = time.perf_counter()
+        if i > 0 and (best is None or t2 - t0 < best):
+            best, parts = t2 - t0, (t1 - t0, t2 - t1)
+    dims = B.MODEL_DIMS["small"]
+    res = {"model": "small", "chunks": 1, "unit": "ms", "value": best * 1e3, "higher_is_better": False,
+           "encode_ms": parts[0] * 1e3, "decode_lid_ms": parts[1] * 1e3, "language": lang, "audio_s_per_s": 30.0 / best,
+           "what": "host f64[480000] -> generate_spectrogram (f64 ABI, host pointers: PCIe in the time) -> f32 -> wm_encode "
+                   "(host in / host out: 4.6 MB of features back over PCIe, as the CoreML call returns them) -> "
+                   "wm_detect_language (features host -> device again, T = 1 step, arg-max over 99 ids); min of 5"}
+    try:   # the CPU oracle on the same flow (checker used as a timed baseline, never as the product)
+        import torch
+        from oracle import whisper_ref as R
+        so = os.path.join(ROOT, "oracle", "liboracle_logmel.so")
+        lib = C.CDLL(so)
+        sd = {n: torch.from_numpy(w.ctx.get_tensor(n, s_)) for n, s_, _ in
+              __import__("importlib").import_module("openai_whisper_coreml_amd.weights").tensor_specs(dims)}
+        buf = np.zeros(480400)
+        out = np.zeros(240000)
+
+        def cpu_flow():
+            buf[:] = 0.0
+            buf[200:480200] = x
+            lib.generate_spectrogram(buf.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+            xa = R.encode(sd, dims, out.astype(np.float32).reshape(1, 80, 3000))
+            return R.detect_language(sd, dims, xa)
+        t_cpu, idx = _best_of(cpu_flow, 2)
+        res["cpu_oracle_ms"] = t_cpu * 1e3
+        res["cpu_oracle_language_matches"] = bool(B.Whisper.LANGUAGES[int(np.asarray(idx).ravel()[0])] == lang)
+        res["cpu_threads"] = torch.get_num_threads()
+    except Exception as e:
+        res["cpu_oracle_ms"] = None
+        res["cpu_oracle_error"] = repr(e)
+    w.ctx.close()
+    return res
+
+
+def frontend_alone(B, pcm16):
+    """The front end ALONE at the reference ABI (stft.swift:8-19 -> `generate_spectrogram`, host f64 in, host f64 out,
+    one chunk per call as the Rust crate is called): audio-s/s with ONE caller and with 8 concurrent caller threads."""
+    x = pcm16[1].astype(np.float64) / 32768.0
+    B.generateSpectrogram(x)                      # warm-up: context of the ABI symbol, tables
+    t1, _ = _best_of(lambda: B.generateSpectrogram(x), 5)
+    n_thr, per = 8, 4
+    def worker():
+        for _ in range(per):
+            B.generateSpectrogram(x)
+    ths = [threading.Thread(target=worker) for _ in range(n_thr)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    t8 = time.perf_counter() - t0
+    return {"unit": "audio-sec/s", "value": 30.0 / t1, "one_caller_ms_per_chunk": t1 * 1e3,
+            "eight_callers_audio_s_per_s": 30.0 * n_thr * per / t8,
+            "what": "generate_spectrogram(double*, double*) through ctypes: 3.84 MB in + 1.92 MB out over PCIe per chunk "
+                    "(f64), kernel time ~0.1 ms: the call is bound by the host copies and the Python wrapper's buffers"}
 
 
 def effective_cores():
@@ -331,6 +432,22 @@ def main():
                          "process at the timed group size)")
     args = ap.parse_args()
 
+    # --gpus N decides the world size (it used to be parsed and never used).  Under a launcher
+    # (torch.distributed.run sets WORLD_SIZE) the two must agree; without one, N > 1 starts the N ranks itself.
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: refusing to report a line whose "
+                         "n_gpus would not be what was asked for" % (args.gpus, env_world))
+    if env_world is None and args.gpus > 1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)   # the ranks' stdout is this process's: rank 0's JSON line comes out as before
+
     # One hardware queue per HIP stream (the runtime's default of 4 makes the fifth stream of the process share a queue
     # with an earlier one -- under torch.distributed the null stream and RCCL's streams come first, and two decode lanes
     # on one queue would run one after the other).  Must be in the environment before the HIP runtime initialises.
@@ -349,10 +466,16 @@ def main():
         import torch
         import torch.distributed as dist
         if dist_backend == "nccl":
+            if local_rank >= torch.cuda.device_count():
+                raise SystemExit("bench.py: rank %d has no GPU (%d visible): --gpus %d needs %d devices on this node"
+                                 % (rank, torch.cuda.device_count(), args.gpus, args.gpus))
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
         else:
             dist.init_process_group(backend=dist_backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: the process group has %d ranks, --gpus asked for %d" % (dist.get_world_size(), args.gpus))
+        world = dist.get_world_size()   # from here on: what the backend actually initialised
 
     import importlib
     import openai_whisper_coreml_amd as pkg
@@ -642,7 +765,10 @@ def main():
             "metric": "audio-sec/s (RTF) + decoder tok/s, Whisper-large-v2 30s chunks, 1->8 GPU",
             "value": total_audio / dt,
             "unit": "audio-sec/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_steps_run,
+            "n_gpus": world,   # = the ranks of the initialised process group (== --gpus, checked above)
+            "rccl_ranks": (world if dist_backend == "nccl" else 0) if use_dist else None,   # None: single process, no collective
+            "dist_backend": (dist_backend if use_dist else None),
+            "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_steps_run,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if args.total_chunks > 0 else "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
@@ -656,12 +782,18 @@ def main():
                        "inflight_batches_per_gpu": S * F, "parallelism": "chunk-dp%d" % world,
                        "total_chunks": args.total_chunks if args.total_chunks > 0 else None},
             "rtf": dt / total_audio,
-            "decoder_tok_per_s": (S * nb * world * max_new) / max(stage_s[2], 1e-9),   # S pipelines decode concurrently
+            # THE decoder figure: generated tokens of the whole job / wall time of the whole job
             "tok_per_s_end_to_end": (nb * world * max_new * args.steps) / dt,
+            # a per-lane-stage construction (tokens of S groups / mean decode-stage time of a group): the rate while all S
+            # lanes are in their decode stage, NOT a whole-job figure
+            "decode_stage_tok_per_s_all_lanes": (S * nb * world * max_new) / max(stage_s[2], 1e-9),
             "inflight_batches_per_gpu": S * F,
             # every cross-check of token_checks holds (each one can fail: distinct chunks per group, distinct rows)
-            "tokens_consistent_across_groups": bool(token_checks) and all(token_checks.values()),
+            # null = no cross-check could run with these flags (not the same thing as "inconsistent")
+            "tokens_consistent_across_groups": (all(token_checks.values()) if token_checks else None),
             "token_checks": token_checks,
+            "token_checks_skipped": sorted({"warmup_pass_equals_timed_pass", "first_batch_alone_equals_its_rows_in_group0",
+                                            "group0_eager_single_lane_equals_timed_run"} - set(token_checks)),
             "distinct_token_rows": distinct_rows, "token_rows": int(all_rows.shape[0]),
             "distinct_tokens_per_row": {"min": int(min(per_row)) if per_row else 0,
                                         "mean": float(np.mean(per_row)) if per_row else 0.0},

@@ -102,7 +102,11 @@ WM_API int wm_set_tensor(wm_ctx *ctx, const char *name, const float *data, size_
 WM_API int wm_get_tensor(wm_ctx *ctx, const char *name, float *data, size_t n_elems);
 /* Flat weight file written by openai-whisper-coreml_amd/weights.py (format: the docstring of weights.py). */
 WM_API int wm_load_weights(wm_ctx *ctx, const char *path);
-/* Deterministic synthetic weights generated ON DEVICE (hash-based, approx N(0, std^2));
+/* ---- TEST / BENCHMARK WEIGHTS: NOT FOR PRODUCTION USE.  The two generators below exist because no checkpoint can be
+ * shipped or downloaded where the tests and bench.py run; a deployment loads real weights (wm_load_weights /
+ * wm_set_tensor) and never calls them.  They stay in the product library (not the debug one) for one reason: bench.py's
+ * headline must be measured on libwhisper_mi355x.so itself, with weights whose token streams can fail a cross-check. ----
+ * Deterministic synthetic weights generated ON DEVICE (hash-based, approx N(0, std^2));
  * identical values to weights.synthetic_state_dict(dims, seed) on the host. */
 WM_API int wm_init_synthetic(wm_ctx *ctx, uint64_t seed);
 /* The same generator with every weight MATRIX (conv / linear / token embedding; not the positional tables, biases or

@@ -21,7 +21,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WM_LIB_PATH") or os.path.join(HERE, "libwhisper_mi355x.so")   # WM_LIB_PATH: A/B builds
 # the product objects + the wmdbg_* kernel test hooks (include/whisper_mi355x_debug.h): tests / tools only
-DEBUG_LIB_PATH = os.path.join(HERE, "libwhisper_mi355x_dbg.so")
+DEBUG_LIB_PATH = os.environ.get("WM_DBG_LIB_PATH") or os.path.join(HERE, "libwhisper_mi355x_dbg.so")   # A/B builds (tools/)
 
 WM_OK = 0
 WM_I16, WM_F32, WM_F64, WM_BF16 = 0, 1, 2, 3

@@ -25,6 +25,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-I", os.path.join(ROOT, "include")] + os.environ.get("WM_EXTRA_HIPCC_FLAGS", "").split()
 
 
+# Per-file flags.  dec_kernels.hip: the first 14 dwords of a decode kernel's (scalar) argument list are placed in SGPRs by
+# the dispatcher, so the first weight / K-V loads of the latency-bound decode chain do not wait for a kernarg fetch
+# (kernel signatures are ordered for it: see dec_gemv_kernel / dec_rows_attn_kernel).
+FILE_FLAGS = {"dec_kernels.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=16"]}
+if os.environ.get("WM_NO_KERNARG_PRELOAD"):   # A/B builds (tools/): same kernels, arguments fetched by s_load
+    FILE_FLAGS = {}
+
+
 def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
@@ -44,7 +52,7 @@ def _compile(src, force, hdr_t):
     if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(s)
             and os.path.getmtime(obj) >= hdr_t):
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", s, "-o", obj]
+    cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(src, []) + ["-x", "hip", "-c", s, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

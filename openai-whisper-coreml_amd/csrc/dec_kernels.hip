@@ -332,20 +332,34 @@ __device__ __forceinline__ void gemv_unit_epilogue(const DecGemvDev &p, const Ge
 // than one batch block its (tile, block) grid then fits one residency round of the chip instead of two (one extra L2
 // round trip inside the workgroup, a whole kernel time saved).  The parts, their MFMA chains and the order they are
 // added in are the same: bit-identical results.
+// KERNEL ARGUMENTS (round 5).  The compiler fetches the fields of a by-value struct lazily, one s_load per first use: the
+// round-4 kernel walked FOUR dependent scalar round trips (bgroups -> n_tg -> pf fields -> W, a, K) before its first weight
+// load was even issued, and a scalar load of a fresh dispatch misses the scalar cache (invalidated at the kernel boundary).
+// Now everything on the path to the first weight load is a leading SCALAR parameter: one s_load burst at most, and with
+// -mllvm -amdgpu-kernarg-preload-count=16 (build.py, this file only) the dispatcher places those 16 dwords in SGPRs
+// before the first instruction (a by-value struct is never preloaded).  The cold fields stay in the struct; they are
+// requested in one burst right after the weight / activation loads (GEMV_PIN below).
+#define GEMV_PIN(x) asm volatile("" ::"s"(x))
 template <int SPW, int TN, int NBLK, int EPI, bool LN, int PPW = 1>
-__global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512 : 1024) void dec_gemv_kernel(DecGemvDev p) {
+__global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512 : 1024) void dec_gemv_kernel(
+    const bf16_t *__restrict__ hotW, const bf16_t *__restrict__ hotA, const int *__restrict__ hot_pos_ptr,
+    const float *__restrict__ hot_c2, int hotK, int hot_n_tiles, int hotB, int hot_bgroups, int hot_n_tg, int hot_n_tg_pad,
+    float *hot_out_f32, DecGemvDev pc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    DecGemvDev p = pc;  // (scalarised by the compiler: a field is a kernarg load at its first use)
+    p.W = hotW; p.a = hotA; p.pos_ptr = hot_pos_ptr; p.c2 = hot_c2; p.K = hotK; p.n_tiles = hot_n_tiles; p.B = hotB;
+    p.bgroups = hot_bgroups; p.n_tg = hot_n_tg; p.n_tg_pad = hot_n_tg_pad; p.out_f32 = hot_out_f32;
     constexpr int NU = TN * NBLK;
-    const int NW = blockDim.x >> 6;
-    const int NP = NW * PPW;  // K parts
+    const int NP = (p.K >> 5) / SPW;  // K parts (blockDim.x lives in the hidden kernel arguments: one more scalar round trip)
+    const int NW = NP / PPW;
     // Workgroup id -> (tile group, batch group): ids 8q .. 8q+7 are tile groups 8(q / G) .. +7 of batch group q % G, so
     // the workgroups of a tile group are dispatched back to back AND on the same XCD (id % 8): the later ones read the
     // weights from the L2 the first one filled -- one HBM stream per tile.  (G == 1: id == tile group.)
     const int G = p.bgroups;
     const int wg = blockIdx.x;
     const int q = wg >> 3;
-    const int tg = (q / G) * 8 + (wg & 7);
-    const int grp = q % G;
+    const int tg = G == 1 ? wg : (q / G) * 8 + (wg & 7);
+    const int grp = G == 1 ? 0 : q % G;
     if (wg >= p.n_tg_pad * G || tg >= p.n_tg) {  // workgroup-uniform: warm-up workgroups and padding
         const int t = wg - p.n_tg_pad * G;
         if (t >= 0 && t < p.pf_tiles) l2_warm_tile(p.pf_ptr, p.pf_tile_bytes, t, NW * 64);
@@ -395,6 +409,16 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
         }
     };
     load_af(wave);
+    // ... the cold kernel arguments, ONE scalar burst behind the loads above ...
+    GEMV_PIN(p.N); GEMV_PIN(p.ldo);
+    if (LN) { GEMV_PIN(p.c1); GEMV_PIN(p.stats_in); GEMV_PIN(p.stats_stride); GEMV_PIN(p.mean_in); GEMV_PIN(p.mean_out); }
+    if (EPI == DE_RESID) { GEMV_PIN(p.out_bf16); GEMV_PIN(p.stats_out); GEMV_PIN(p.stats_stride); GEMV_PIN(p.mean_in); }
+    if (EPI == DE_QKV) { GEMV_PIN(p.kcache); GEMV_PIN(p.vcache); GEMV_PIN(p.n_ctx); GEMV_PIN(p.n_head); }
+    if (EPI == DE_GELU) GEMV_PIN(p.out_bf16);
+    if (EPI == DE_LOGITS) {
+        GEMV_PIN(p.tilemax); GEMV_PIN(p.arg_first); GEMV_PIN(p.arg_last); GEMV_PIN(p.mask); GEMV_PIN(p.mask_words);
+        GEMV_PIN(p.mask_first_pos); GEMV_PIN(p.ts.rng); GEMV_PIN(p.ts.key_ts); GEMV_PIN(p.ts.lse); GEMV_PIN(p.ts.ts_begin);
+    }
     // ... and the epilogue operands of the (tile, block) unit this wave will finish: unit u = j * TN + t -> wave u % NW
     int pos = 0;
     unsigned mword0 = 0u, mword1 = 0u;
@@ -574,32 +598,42 @@ __device__ __forceinline__ float attn_merge(const float *m, const float *l, cons
     return attn_merge_core<NS>(mm, ll, oo);
 }
 
+// KERNEL ARGUMENTS / FIRST LOADS (round 5).  The round-4 kernel reached its first K/V load after six to seven DEPENDENT
+// memory round trips (three lazy kernarg bursts, *n_live_ptr, *pos_ptr, live_rows[..], the query), each a cache miss on
+// a fresh dispatch: 5.0 us for the ~1 MB self-attention of a batch of 8.  Now (a) the first 15 dwords of the argument
+// list are everything the first loads need (small integers packed), so with -amdgpu-kernarg-preload-count=16 they are
+// in SGPRs at the first instruction; (b) the position, the live count and the first pair's live row are requested
+// TOGETHER, from always-valid addresses (a null pointer is replaced by `q`, the value discarded); (c) the query and the
+// FIRST block of K/V rows of the first pair are requested before any of those values is needed: a self-attention row
+// index is clamped to the cache's last row (T_stride - 1, an argument) instead of to the position, the rows past the
+// position are masked as before and their V words zeroed (they may hold anything, and 0 x NaN must not reach the sum).
+// The arithmetic -- blocks, order, merge -- is unchanged: same bits.
+struct AttnCold {
+    bf16_t *att;
+    float *part;
+    const char *pf_ptr;
+    long pf_tile_bytes;
+};
 template <int NS, int U, bool NT, bool DEEP = false>
-__global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_rows_attn_kernel(const float *__restrict__ q,
-                                                                const bf16_t *__restrict__ kc,
-                                                                const bf16_t *__restrict__ vc, int H, int d,
-                                                                int T_stride, int n_keys_const,
-                                                                const int *__restrict__ pos_ptr,
-                                                                bf16_t *__restrict__ att, float *__restrict__ part,
-                                                                int nsplit, int n_bh, int n_wg,
-                                                                const char *pf_ptr, long pf_tile_bytes, int flat_wpw,
-                                                                const int *__restrict__ live_rows,
-                                                                const int *__restrict__ n_live_ptr) {
+__global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_rows_attn_kernel(
+    const float *__restrict__ q, const bf16_t *__restrict__ kc, const bf16_t *__restrict__ vc,
+    const int *__restrict__ pos_ptr, const int *__restrict__ live_rows /* [WM_DEC_MAXB] rows | [1] count, or null */,
+    unsigned packA /* H | nsplit << 8 | flat_wpw << 16 */, unsigned packB /* T_stride | n_keys_const << 16 */,
+    unsigned packC /* n_bh | n_wg << 16 */, AttnCold cold) {
+    const int H = (int)(packA & 0xffu), nsplit = (int)((packA >> 8) & 0xffu), flat_wpw = (int)(packA >> 16);
+    const int T_stride = (int)(packB & 0xffffu), n_keys_const = (int)(packB >> 16);
+    const int n_bh_full = (int)(packC & 0xffffu), n_wg = (int)(packC >> 16);
+    const int d = H * 64;
+    const int *n_live_ptr = live_rows ? live_rows + WM_DEC_MAXB : nullptr;
+    constexpr bool SELF = NS == 4;  // the causal self-attention: the key count is the device-side position
     if ((int)blockIdx.x >= n_wg) {  // L2 warm-up workgroup for the next GEMV's weights
-        l2_warm_tile(pf_ptr, pf_tile_bytes, (int)blockIdx.x - n_wg, blockDim.x);
+        l2_warm_tile(cold.pf_ptr, cold.pf_tile_bytes, (int)blockIdx.x - n_wg, blockDim.x);
         return;
     }
-    // Early stop: sequences that have emitted <|endoftext|> (or used up their token budget) leave the decode group.
-    // The arg-max kernel keeps a COMPACT list of the live rows; the pairs walked here are (live row, head), dealt to the
-    // workgroups exactly like the full set, so the cache of a finished sequence is never read again and the remaining
-    // pairs stay balanced over the chip.  (null: every row is live -- the fixed-length benchmark decode.)
-    if (n_live_ptr) n_bh = *n_live_ptr * H;
     __shared__ float wm_[NS], wl_[NS];
     __shared__ float wo_[NS][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rg = lane >> 3, e8 = lane & 7;
-    const int n_keys = pos_ptr ? (*pos_ptr + 1) : n_keys_const;
-    const int last = n_keys - 1;
     // FLAT launch (few pairs): the n_bh * NS (pair, stream) units are dealt to the waves of the grid one to one,
     // flat_wpw waves per workgroup, so that every CU streams an equal share whatever the pair count (B = 8 x 20 heads:
     // 1280 units = 256 workgroups of 5 waves); the waves of a workgroup are independent (partials to `part`, no barrier).
@@ -607,41 +641,85 @@ __global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_rows_attn_kernel(con
     int bh0 = blockIdx.x, bh_step = n_wg;
     if (flat_wpw > 0) {
         const int unit = (int)blockIdx.x * flat_wpw + wave;
-        if (unit >= n_bh * NS) return;  // wave-uniform
+        if (unit >= n_bh_full * NS) return;  // wave-uniform
         bh0 = unit / NS;
         stream = unit % NS;
-        bh_step = n_bh;  // one pair per wave
+        bh_step = n_bh_full;  // one pair per wave
     }
+    // ---- scalar burst: position, live count, the first pair's live row -- unconditional loads, valid addresses
+    const int *dummy = (const int *)q;
+    const int pos_raw = *(pos_ptr ? pos_ptr : dummy);
+    const int nl_raw = *(n_live_ptr ? n_live_ptr : dummy);
+    // Early stop: sequences that have emitted <|endoftext|> (or used up their token budget) leave the decode group.
+    // The arg-max kernel keeps a COMPACT list of the live rows; the pairs walked here are (live row, head), dealt to the
+    // workgroups exactly like the full set, so the cache of a finished sequence is never read again and the remaining
+    // pairs stay balanced over the chip.  (null: every row is live -- the fixed-length benchmark decode.)
+    const int n_clamp = SELF ? T_stride - 1 : n_keys_const - 1;  // known without a load: the first block's row clamp
+    auto load_block = [&](const bf16_t *kb, const bf16_t *vb, int r0, int clamp, u32x4 (&kv)[U], u32x4 (&vv)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int i = r0 + u * (NS * 8) + stream * 8 + rg;
+            i = i < clamp ? i : clamp;  // clamped: unconditional loads
+            if (NT) {
+                kv[u] = __builtin_nontemporal_load((const u32x4 *)(kb + (long)i * 64));
+                vv[u] = __builtin_nontemporal_load((const u32x4 *)(vb + (long)i * 64));
+            } else {
+                kv[u] = *(const u32x4 *)(kb + (long)i * 64);
+                vv[u] = *(const u32x4 *)(vb + (long)i * 64);
+            }
+        }
+    };
+    // every load of a block is IN FLIGHT before its first score is computed: the 2 U values pass through one empty asm, so
+    // nothing of the block can be consumed before all of it was requested (round 5: a re-ordered argument list was enough
+    // for the compiler to issue 6 of the 8 loads, start on the scores, and issue the last two afterwards -- 13.7 -> 16.5 us
+    // at 8 sequences: the stream is bound by bytes in flight per CU)
+    auto block_fence = [](u32x4 (&kv)[U], u32x4 (&vv)[U]) {
+        static_assert(U == 4, "block_fence is written for 4 loads per block");
+        asm volatile("" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]));
+    };
+    bool first = true;
+    int n_bh = n_bh_full, n_keys = n_keys_const;
     // n_wg <= n_bh workgroups (per split) walk the (sequence, head) pairs
     for (int pi = bh0; pi < n_bh; pi += bh_step) {
-        if (flat_wpw == 0 && pi != (int)blockIdx.x) __syncthreads();  // the previous pair's merge has been read
+        if (flat_wpw == 0 && !first) __syncthreads();  // the previous pair's merge has been read
         const int h = pi % H;
-        const int b = live_rows ? live_rows[pi / H] : pi / H;
+        int b = pi / H;
+        if (live_rows) b = live_rows[pi / H];  // first pair: pi < n_bh_full, a (possibly stale) valid row id
         const int bh = b * H + h;
         const bf16_t *kb = kc + (long)bh * T_stride * 64 + e8 * 8;
         const bf16_t *vb = vc + (long)bh * T_stride * 64 + e8 * 8;
-        float qe[8];
-        {
-            const float *qp = q + (long)b * d + h * 64 + e8 * 8;
+        const f32x4 *qp = (const f32x4 *)(q + (long)b * d + h * 64 + e8 * 8);
+        const f32x4 q0 = qp[0], q1 = qp[1];
+        // SPEC: the first block (DEEP: every block) of this stream is requested BEFORE the position / live count is looked
+        // at.  The streaming shape of the cross-attention (NS = 8, block by block) keeps the round-4 loop: its key count is
+        // an argument, its time is the stream, and the compiler's schedule of that loop (all 2 U loads of a block issued
+        // together) is what the 6.4 TB/s were measured with.
+        constexpr bool SPEC = SELF || DEEP;
+        constexpr int NB = DEEP ? ATT_MAXK / (NS * 8 * U) : 1;
+        u32x4 kall[NB][U], vall[NB][U];
+        if (SPEC) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) qe[i] = qp[i] * 0.125f;  // hd^-0.5 (== hd^-0.25 on q and on k)
+            for (int blk = 0; blk < NB; ++blk)
+                load_block(kb, vb, blk * (NS * 8 * U), first ? n_clamp : n_keys - 1, kall[blk], vall[blk]);
+        }
+        if (first) {
+            // (the empty asm ties the first USE of the two scalar loads to the arrival of the query: without it the
+            // compiler hoists `pos + 1` in front of the loop and waits for the scalar loads before issuing the K/V loads)
+            int pos_v = pos_raw, nl_v = nl_raw;
+            if (SPEC) asm volatile("" : "+s"(pos_v), "+s"(nl_v) : "v"(q0[0]));
+            if (n_live_ptr) n_bh = nl_v * H;
+            if (pos_ptr) n_keys = pos_v + 1;
+            first = false;
+            if (pi >= n_bh) break;  // (workgroup- / wave-uniform) the speculative pair is not live
+        }
+        float qe[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qe[i] = q0[i] * 0.125f;  // hd^-0.5 (== hd^-0.25 on q and on k)
+            qe[4 + i] = q1[i] * 0.125f;
         }
         float m_run = -1e30f, l_run = 0.f;
         float oa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        auto load_block = [&](int r0, u32x4 (&kv)[U], u32x4 (&vv)[U]) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                int i = r0 + u * (NS * 8) + stream * 8 + rg;
-                i = i < n_keys ? i : last;  // clamped: unconditional loads
-                if (NT) {
-                    kv[u] = __builtin_nontemporal_load((const u32x4 *)(kb + (long)i * 64));
-                    vv[u] = __builtin_nontemporal_load((const u32x4 *)(vb + (long)i * 64));
-                } else {
-                    kv[u] = *(const u32x4 *)(kb + (long)i * 64);
-                    vv[u] = *(const u32x4 *)(vb + (long)i * 64);
-                }
-            }
-        };
         // one block of U x 8 rows of this stream: scores, block maximum, rescale, accumulate -- the stream's arithmetic
         auto process_block = [&](int r0, const u32x4 (&kv)[U], const u32x4 (&vv)[U]) {
             float sc[U];
@@ -671,31 +749,35 @@ __global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_rows_attn_kernel(con
             for (int j = 0; j < 8; ++j) oa[j] *= resc;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const float pv = sc[u] > -1e29f ? __expf(sc[u] - m_new) : 0.f;
+                const bool live_row = sc[u] > -1e29f;
+                const float pv = live_row ? __expf(sc[u] - m_new) : 0.f;
                 l_run += pv;  // the 8 lanes of a row hold the same pv: only the row groups are summed below
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    oa[2 * j] = __fmaf_rn(pv, __uint_as_float(vv[u][j] << 16), oa[2 * j]);
-                    oa[2 * j + 1] = __fmaf_rn(pv, __uint_as_float(vv[u][j] & 0xffff0000u), oa[2 * j + 1]);
+                    // SELF: a row past the position was read from wherever the clamp pointed -- never let its bits in
+                    const unsigned vw = (SELF && !live_row) ? 0u : vv[u][j];
+                    oa[2 * j] = __fmaf_rn(pv, __uint_as_float(vw << 16), oa[2 * j]);
+                    oa[2 * j + 1] = __fmaf_rn(pv, __uint_as_float(vw & 0xffff0000u), oa[2 * j + 1]);
                 }
             }
             m_run = m_new;
         };
         if (DEEP) {
             // LATENCY shape (a handful of pairs: tiny.en single chunk = 48 waves on the whole chip): a stream's rows are
-            // <= 6 blocks, and walking them one dependent memory round trip at a time was 9.2 us for 2.3 MB.  Request
-            // EVERY block first (48 x 16 B per lane), then run the same block arithmetic in the same order: same bits.
-            constexpr int NB = ATT_MAXK / (NS * 8 * U);
-            u32x4 kall[NB][U], vall[NB][U];
-#pragma unroll
-            for (int blk = 0; blk < NB; ++blk) load_block(blk * (NS * 8 * U), kall[blk], vall[blk]);
+            // <= 6 blocks, and walking them one dependent memory round trip at a time was 9.2 us for 2.3 MB.  EVERY block
+            // was requested above (48 x 16 B per lane); the same block arithmetic in the same order: same bits.
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk)
                 if (blk * (NS * 8 * U) < n_keys) process_block(blk * (NS * 8 * U), kall[blk], vall[blk]);  // workgroup-uniform
         } else {
-            for (int r0 = 0; r0 < n_keys; r0 += NS * 8 * U) {  // workgroup-uniform trip count
+            if (SPEC) {
+                block_fence(kall[0], vall[0]);
+                process_block(0, kall[0], vall[0]);
+            }
+            for (int r0 = SPEC ? NS * 8 * U : 0; r0 < n_keys; r0 += NS * 8 * U) {  // workgroup-uniform trip count
                 u32x4 kv[U], vv[U];
-                load_block(r0, kv, vv);
+                load_block(kb, vb, r0, n_keys - 1, kv, vv);
+                block_fence(kv, vv);
                 process_block(r0, kv, vv);
             }
         }
@@ -710,7 +792,7 @@ __global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_rows_attn_kernel(con
         l_run += __shfl_xor(l_run, 32);
         if (nsplit > 1) {  // workgroup-uniform: the stream partials go to HBM, dec_attn_combine_kernel merges them
             if (rg == 0) {
-                float *po = part + ((long)bh * NS + stream) * 66;
+                float *po = cold.part + ((long)bh * NS + stream) * 66;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) po[2 + e8 * 8 + i] = oa[i];
                 if (e8 == 0) {
@@ -730,7 +812,7 @@ __global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_rows_attn_kernel(con
         }
         __syncthreads();
         if (tid < 64)  // head outputs feed the out-projection GEMV: stored in its fragment-tiled A-operand order
-            att[wm_tiled_offset((size_t)b, (size_t)(h * 64 + tid), (size_t)d)] = f2bf(attn_merge<NS>(wm_, wl_, &wo_[0][0], 64, tid));
+            cold.att[wm_tiled_offset((size_t)b, (size_t)(h * 64 + tid), (size_t)d)] = f2bf(attn_merge<NS>(wm_, wl_, &wo_[0][0], 64, tid));
     }
 }
 
@@ -742,12 +824,20 @@ __global__ __launch_bounds__(64) void dec_attn_combine_kernel(const float *__res
     __shared__ float wm_[NS], wl_[NS];
     const int bh = blockIdx.x, b = bh / H, h = bh % H, e = threadIdx.x;
     const float *pp = part + (long)bh * NS * 66;
+    float oo[NS], mm[NS], ll[NS];
+#pragma unroll
+    for (int w = 0; w < NS; ++w) oo[w] = pp[2 + w * 66 + e];  // requested together with (m, l): ONE memory round trip
     if (e < NS) {
         wm_[e] = pp[e * 66];
         wl_[e] = pp[e * 66 + 1];
     }
     __syncthreads();
-    att[wm_tiled_offset((size_t)b, (size_t)(h * 64 + e), (size_t)d)] = f2bf(attn_merge<NS>(wm_, wl_, pp + 2, 66, e));
+#pragma unroll
+    for (int w = 0; w < NS; ++w) {
+        mm[w] = wm_[w];
+        ll[w] = wl_[w];
+    }
+    att[wm_tiled_offset((size_t)b, (size_t)(h * 64 + e), (size_t)d)] = f2bf(attn_merge_core<NS>(mm, ll, oo));
 }
 
 // ------------------------------------------------------------------ arg-max -> next token
@@ -770,7 +860,10 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
     __shared__ int tok_s[16];
     __shared__ int is_last_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int pos = pos_ptr ? *pos_ptr : 0;
+    // the position is requested now and first USED after the per-tile maxima have been requested (the empty asm below
+    // ties its use to the first of them): the round-4 kernel waited for it before issuing a single load
+    const int pos_raw = *(pos_ptr ? pos_ptr : (const int *)tilemax);
+    int pos = 0;
     const int bw = blockIdx.x * 16;  // this workgroup's rows: one per wave
     for (int b = bw + wave; b < B && b < bw + 16; b += 16) {  // wave-uniform, at most one trip
         const unsigned long long *row = tilemax + (long)b * n_tiles;
@@ -784,6 +877,11 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) key = k[u] > key ? k[u] : key;
+        }
+        {
+            int pv = pos_raw;
+            asm volatile("" : "+s"(pv) : "v"((unsigned)key));
+            pos = pos_ptr ? pv : 0;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -863,6 +961,11 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
         }
     }
     __syncthreads();
+    {   // (waves without a row of their own have not looked at the position yet)
+        int pv = pos_raw;
+        asm volatile("" : "+s"(pv));
+        pos = pos_ptr ? pv : 0;
+    }
     if (x && pos + 1 < n_ctx) {
         for (int b = bw + wave; b < B && b < bw + 16; b += 16) {
             const long tok = tok_s[b - bw];
@@ -986,6 +1089,7 @@ __global__ __launch_bounds__(256) void synth_fill_kernel(void *dst, int is_bf16,
     }
 }
 
+#define GEMV_ARGS(p) (p).W, (p).a, (p).pos_ptr, (p).c2, (p).K, (p).n_tiles, (p).B, (p).bgroups, (p).n_tg, (p).n_tg_pad, (p).out_f32, (p)
 template <int SPW, int EPI, bool LN>
 int launch_gemv_shape(wm_ctx *ctx, const DecGemvDev &p, int tn, int nblk, int nw, int grid, int ppw) {
     hipStream_t s = ctx->stream;
@@ -994,19 +1098,19 @@ int launch_gemv_shape(wm_ctx *ctx, const DecGemvDev &p, int tn, int nblk, int nw
         if (!TWO || tn != 1 || nblk != 1 || nw % 2) { wm_set_error("dec_gemv: no two-part kernel for this shape"); return WM_ERR_INVALID; }
         const int w2 = nw / 2;
         const size_t lds2 = (size_t)nw * 1024 + (size_t)w2 * 32 * 4;
-        dec_gemv_kernel<TWO ? SPW : 6, 1, 1, TWO ? EPI : DE_RESID, TWO ? LN : false, 2><<<grid, w2 * 64, lds2, s>>>(p);
+        dec_gemv_kernel<TWO ? SPW : 6, 1, 1, TWO ? EPI : DE_RESID, TWO ? LN : false, 2><<<grid, w2 * 64, lds2, s>>>(GEMV_ARGS(p));
         WM_HIP(hipGetLastError());
         return WM_OK;
     }
     const size_t lds = (size_t)nw * tn * nblk * 1024 + (size_t)nw * 32 * 4;
     const int th = nw * 64;
     constexpr bool WIDE = LN && (EPI == DE_QKV || EPI == DE_GELU || EPI == DE_LOGITS) && SPW <= 6;
-    if (tn == 1 && nblk == 1) dec_gemv_kernel<SPW, 1, 1, EPI, LN><<<grid, th, lds, s>>>(p);
-    else if (tn == 1 && nblk == 2 && SPW <= 8) dec_gemv_kernel<SPW <= 8 ? SPW : 2, 1, 2, EPI, LN><<<grid, th, lds, s>>>(p);
-    else if (tn == 2 && nblk == 1 && WIDE && EPI == DE_LOGITS) dec_gemv_kernel<WIDE ? SPW : 2, 2, 1, WIDE ? EPI : DE_LOGITS, LN><<<grid, th, lds, s>>>(p);
-    else if (tn == 4 && nblk == 1 && WIDE && EPI == DE_LOGITS) dec_gemv_kernel<WIDE ? SPW : 2, 4, 1, WIDE ? EPI : DE_LOGITS, LN><<<grid, th, lds, s>>>(p);
-    else if (tn == 2 && nblk == 2 && WIDE) dec_gemv_kernel<WIDE ? SPW : 2, 2, 2, EPI, LN><<<grid, th, lds, s>>>(p);
-    else if (tn == 4 && nblk == 2 && WIDE) dec_gemv_kernel<WIDE ? SPW : 2, 4, 2, EPI, LN><<<grid, th, lds, s>>>(p);
+    if (tn == 1 && nblk == 1) dec_gemv_kernel<SPW, 1, 1, EPI, LN><<<grid, th, lds, s>>>(GEMV_ARGS(p));
+    else if (tn == 1 && nblk == 2 && SPW <= 8) dec_gemv_kernel<SPW <= 8 ? SPW : 2, 1, 2, EPI, LN><<<grid, th, lds, s>>>(GEMV_ARGS(p));
+    else if (tn == 2 && nblk == 1 && WIDE && EPI == DE_LOGITS) dec_gemv_kernel<WIDE ? SPW : 2, 2, 1, WIDE ? EPI : DE_LOGITS, LN><<<grid, th, lds, s>>>(GEMV_ARGS(p));
+    else if (tn == 4 && nblk == 1 && WIDE && EPI == DE_LOGITS) dec_gemv_kernel<WIDE ? SPW : 2, 4, 1, WIDE ? EPI : DE_LOGITS, LN><<<grid, th, lds, s>>>(GEMV_ARGS(p));
+    else if (tn == 2 && nblk == 2 && WIDE) dec_gemv_kernel<WIDE ? SPW : 2, 2, 2, EPI, LN><<<grid, th, lds, s>>>(GEMV_ARGS(p));
+    else if (tn == 4 && nblk == 2 && WIDE) dec_gemv_kernel<WIDE ? SPW : 2, 4, 2, EPI, LN><<<grid, th, lds, s>>>(GEMV_ARGS(p));
     else { wm_set_error("dec_gemv: unsupported launch shape (tn %d, nblk %d, spw %d)", tn, nblk, SPW); return WM_ERR_INVALID; }
     WM_HIP(hipGetLastError());
     return WM_OK;
@@ -1202,6 +1306,8 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
     WM_REQUIRE(T_stride <= ATT_MAXK && n_keys <= ATT_MAXK, WM_ERR_INVALID,
                "dec_attention: more than %d keys", ATT_MAXK);
     WM_REQUIRE(nsplit == 1 || part != nullptr, WM_ERR_INVALID, "dec_attention: split launch without a partials buffer");
+    WM_REQUIRE(H >= 1 && H <= 255 && B * H < 65536, WM_ERR_INVALID, "dec_attention: %d heads x %d rows do not fit the packed arguments", H, B);
+    WM_REQUIRE((!live_rows && !n_live) || n_live == live_rows + WM_DEC_MAXB, WM_ERR_INVALID, "dec_attention: the live count must follow the live rows");
     {
         WmProfScope ps(&ctx->prof, cross ? "dec_attn_cross" : "dec_attn_self", ctx->stream);
         // 8 streams x 4 loads = 126 VGPRs: an 8-wave GEMV workgroup of another decode group fits beside one of these on a
@@ -1229,17 +1335,21 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
             wpw = wpw < 1 ? 1 : (wpw > 4 ? 4 : wpw);   // < 96 pairs = < 768 units: <= 3 (the DEEP kernel is built for <= 4 waves)
             const int g = (units + wpw - 1) / wpw;
             // (DEEP: every block of a stream requested up front -- the flat deal is the latency regime by construction)
+            const AttnCold cold = {att, part, nullptr, 0};
+            const unsigned pA = (unsigned)H | (8u << 8) | ((unsigned)wpw << 16), pB = (unsigned)T_stride | ((unsigned)n_keys << 16);
+            const unsigned pC = (unsigned)(B * H) | ((unsigned)g << 16);
+            WM_REQUIRE(g < 65536, WM_ERR_INVALID, "dec_attention: flat grid too large");
             if (g_wm_tuning.xattn_no_deep)
                 dec_rows_attn_kernel<8, 4, WM_XATTN_NT><<<g, wpw * 64, 0, ctx->stream>>>(
-                    q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, 8, B * H, g, nullptr, 0, wpw, live_rows, n_live);
+                    q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
             // a cache of <= 3.2 MB per layer (tiny.en / base, single chunk) stays in the L2s from one position to the next
             // when it is read with cacheable loads: -1 .. -2 % per position there; +5 % at `small` (4.6 MB): the rule
             else if ((size_t)B * H * T_stride * 64 * 2 * 2 <= (size_t)3200 * 1024)
                 dec_rows_attn_kernel<8, 4, false, true><<<g, wpw * 64, 0, ctx->stream>>>(
-                    q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, 8, B * H, g, nullptr, 0, wpw, live_rows, n_live);
+                    q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
             else
                 dec_rows_attn_kernel<8, 4, WM_XATTN_NT, true><<<g, wpw * 64, 0, ctx->stream>>>(
-                    q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, 8, B * H, g, nullptr, 0, wpw, live_rows, n_live);
+                    q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
         } else {
             dim3 grid(gx, nsplit);
             // ONE cross-attention workgroup per CU, chip-wide: a workgroup reserves more than half of the CU's 160 KB of
@@ -1256,9 +1366,11 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad));
                 pad_set[ctx->device & 63].store(lds_pad, std::memory_order_release);
             }
+            const AttnCold cold = {att, part, (const char *)pf_ptr, tile_bytes};
+            const unsigned pA = (unsigned)H | ((unsigned)nsplit << 8), pB = (unsigned)T_stride | ((unsigned)n_keys << 16);
+            const unsigned pC = (unsigned)(B * H) | ((unsigned)n_wg << 16);
             dec_rows_attn_kernel<8, 4, WM_XATTN_NT><<<grid, (8 / nsplit) * 64, nsplit == 1 ? lds_pad : 0, ctx->stream>>>(
-                q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att, part, nsplit, B * H, n_wg, (const char *)pf_ptr,
-                tile_bytes, 0, live_rows, n_live);
+                q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
         }
         WM_HIP(hipGetLastError());
     }
@@ -1275,6 +1387,8 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
                           const int *live_rows, const int *n_live) {
     WM_REQUIRE(T_stride <= ATT_MAXK && n_keys <= ATT_MAXK && (pos_ptr || n_keys >= 1), WM_ERR_INVALID,
                "dec_self_attention: 1..%d keys", ATT_MAXK);
+    WM_REQUIRE(H >= 1 && H <= 255 && B * H < 65536, WM_ERR_INVALID, "dec_self_attention: %d heads x %d rows do not fit the packed arguments", H, B);
+    WM_REQUIRE((!live_rows && !n_live) || n_live == live_rows + WM_DEC_MAXB, WM_ERR_INVALID, "dec_self_attention: the live count must follow the live rows");
     WmProfScope ps(&ctx->prof, "dec_attn_self", ctx->stream);
     int gx = B * H;
     long tile_bytes = 0;
@@ -1283,9 +1397,10 @@ int wm_dec_self_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const b
         gx += pf_rows / 16;
     }
     // a pair is 15-57 KB of cache (<= 448 rows, ~115 on average over a 224-token decode): ONE 4-wave workgroup
-    dec_rows_attn_kernel<4, 4, false><<<gx, 256, 0, ctx->stream>>>(q, kc, vc, H, H * 64, T_stride, n_keys, pos_ptr, att,
-                                                                  nullptr, 1, B * H, B * H, (const char *)pf_ptr, tile_bytes, 0,
-                                                                  live_rows, n_live);
+    const AttnCold cold = {att, nullptr, (const char *)pf_ptr, tile_bytes};
+    const unsigned pA = (unsigned)H | (1u << 8), pB = (unsigned)T_stride | ((unsigned)n_keys << 16);
+    const unsigned pC = (unsigned)(B * H) | ((unsigned)(B * H) << 16);
+    dec_rows_attn_kernel<4, 4, false><<<gx, 256, 0, ctx->stream>>>(q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

@@ -104,14 +104,16 @@ __device__ __forceinline__ void store_tile(const GemmDev &p, const f32x4 (&acc)[
         const int mb = mrow0 + i * 16;  // first of 4 consecutive rows (mb % 4 == 0)
         if (mb >= p.M) continue;
         if (EPI == EPI_QKV_ENC) {
-            // 4 consecutive frames of one chunk (seq % 4 == 0 is not required: rows are checked) -> one 8-B store
+            // 4 consecutive frames of one chunk -> one 8-B store.  Only when the 4 frames start a 4-key group of the chunk
+            // (sq % 4 == 0: wm_att_vt_pos permutes whole 4-key groups); otherwise -- a chunk length that is not a multiple
+            // of 4 puts later chunks' rows at sq % 4 != 0 -- the per-element path below places every frame on its own
             const unsigned b = (unsigned)mb / seq, sq = (unsigned)mb - b * seq;
             const long roff = (long)b * p.n_head * 64 * p.seq_pad + wm_att_vt_pos(sq);   // sq % 4 == 0: the 4 frames stay together
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 if (!vpart[j] || ncol0 + j * 16 >= p.N) continue;
                 const f32x4 &c = acc[i][j];
-                if (sq + 3 < seq && mb + 3 < p.M) {
+                if ((sq & 3u) == 0 && sq + 3 < seq && mb + 3 < p.M) {
                     unsigned lo = (unsigned)f2bf(c[0] + bv[j]) | ((unsigned)f2bf(c[1] + bv[j]) << 16);
                     unsigned hi = (unsigned)f2bf(c[2] + bv[j]) | ((unsigned)f2bf(c[3] + bv[j]) << 16);
                     *(uint2 *)(p.vt + roff + coff[j]) = make_uint2(lo, hi);

@@ -61,8 +61,8 @@ static int alloc_decode_buffers(WmModel *m, hipStream_t s) {
     WM_TRY(dalloc_t(m, &m->darrive, 4, s));
     WM_TRY(dalloc_t(m, &m->ddone, WM_DEC_MAXB, s));
     WM_TRY(dalloc_t(m, &m->dbudget, WM_DEC_MAXB, s));
-    WM_TRY(dalloc_t(m, &m->dlive, WM_DEC_MAXB, s));
-    WM_TRY(dalloc_t(m, &m->dnlive, 4, s));
+    WM_TRY(dalloc_t(m, &m->dlive, WM_DEC_MAXB + 4, s));   // [live rows | n_live]: ONE pointer argument for the attention
+    m->dnlive = m->dlive + WM_DEC_MAXB;                  // kernels (their first loads need everything in 14 dwords)
     if (!m->h_nlive) WM_HIP(hipHostMalloc((void **)&m->h_nlive, WM_NLIVE_RING * sizeof(int), hipHostMallocDefault));
     WM_TRY(dalloc_t(m, &m->dts_rng, (size_t)WM_DEC_MAXB * 4, s));
     WM_TRY(dalloc_t(m, &m->dts_hist, (size_t)WM_DEC_MAXB * 4, s));

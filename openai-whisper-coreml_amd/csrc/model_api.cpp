@@ -564,8 +564,9 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
     // them on L lanes.  Per-kernel profiling keeps everything on the caller's context (one lane).
     const int L = ctx->prof.on ? 1 : (ctx->max_lanes > 0 ? ctx->max_lanes : lane_limit());
     int G;
-    if (B <= kGroupChunks * L) {
-        G = (B + kGroupChunks - 1) / kGroupChunks;
+    const int gc = g_wm_tuning.group_chunks > 0 ? g_wm_tuning.group_chunks : kGroupChunks;   // (probes only; 0 in the product)
+    if (B <= gc * L) {
+        G = (B + gc - 1) / gc;
     } else {
         G = (B + WM_DEC_MAXB - 1) / WM_DEC_MAXB;
         if (G < L) G = L;
@@ -624,7 +625,7 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
                 if (j.t < n_steps && !j.stopped) {
                     // does this burst share the chip?  other lanes of this call still decoding, or other calls in flight
                     int busy = 0;
-                    for (int o = 0; o < n_lanes; ++o) busy += jobs[o].state == LaneJob::DECODING && jobs[o].t < n_steps;
+                    for (int o = 0; o < n_lanes; ++o) busy += jobs[o].state == LaneJob::DECODING && jobs[o].t < n_steps && !jobs[o].stopped;
                     const bool shared = busy > 1 || g_wm_active_decodes[ctx->device & 63].load(std::memory_order_relaxed) > 1;
                     WM_TRY(lane_burst(j, n_prompt, n_steps, use_graph, stop.on, shared));
                     progress = true;

@@ -131,3 +131,31 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert line["tokens_consistent_across_groups"] is True
     assert line["config"]["parallelism"] == "chunk-dp2"
     assert line["value"] > 0 and abs(line["value"] - 30.0 * 8 * 2 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
+
+
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`--gpus N` used to be parsed and ignored (the world size came from WORLD_SIZE only), so
+    `python bench.py --gpus 8` without a launcher would have been a one-GPU run reporting n_gpus 1.  Now bench.py
+    re-executes itself under torch.distributed.run when no launcher is present: here N = 2 with NO launcher, both ranks on
+    device 0 over gloo (RCCL refuses two ranks on one device), and N = 1 as the driver runs it."""
+    env = dict(os.environ, WM_BENCH_DIST_BACKEND="gloo", WM_BENCH_NO_INSITU="1", HIP_VISIBLE_DEVICES="0", WM_BENCH_LOCAL_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    common = ["--steps", "3", "--warmup", "1", "--model", "base", "--new-tokens", "16", "--no-cpu-baseline", "--no-early-stop",
+              "--no-other-configs"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, capture_output=True, text=True,
+                       timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["dist_backend"] == "gloo" and two["rccl_ranks"] == 0
+    assert two["config"]["parallelism"] == "chunk-dp2" and two["tokens_consistent_across_groups"] is True
+    env1 = {k: v for k, v in env.items() if k not in ("WM_BENCH_DIST_BACKEND", "WM_BENCH_LOCAL_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True,
+                       timeout=900, env=env1, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    one = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert one["n_gpus"] == 1 and one["rccl_ranks"] is None and one["dist_backend"] is None
+    # weak scaling over the same device: two ranks time-share one GPU, so the pair cannot be faster than ~1x one rank
+    assert two["value"] > 0.4 * one["value"]

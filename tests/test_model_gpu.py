@@ -897,6 +897,45 @@ def test_large_v3_full_depth_one_chunk(pkg):
     ctx.close()
 
 
+def test_large_v3_fifteen_chunk_shard_on_the_products_own_lanes(pkg):
+    """BASELINE.json configs[4] at its PER-GPU size: 1 h of audio = 120 chunks over 8 GPUs = 15 chunks per rank, large-v3 at
+    FULL depth (128 mel bins, 51 866 tokens), through wm_transcribe_greedy with the product's DEFAULT group / lane policy
+    (model_api.cpp: 15 chunks -> decode groups of 8 + 7 on two weight-sharing lanes).  15 distinct recordings, `lively`
+    weights with perturbed LayerNorms; every row must equal the row of the same chunk decoded ALONE (one chunk per call:
+    a one-row group, other launch shapes, no lanes), the rows must be pairwise distinct, and three of them are
+    teacher-forced against the fp32 oracle over all their tokens."""
+    import torch
+    dims = pkg.binding.MODEL_DIMS["large-v3"]
+    ctx = pkg.binding.Context(dims)
+    ctx.init_synthetic(20240928, matrix_gain=LIVELY_GAIN)
+    _perturb_ln_on_device(ctx, dims, seed=11)
+    ctx.finalize()
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    pcm = np.stack([tone_chunk(i) if i % 3 == 0 else L.synth_chunk(200 + i) for i in range(15)])
+    prompt = [50258, 50259, 50360, 50364]
+    NEW = 48
+    ctx.set_lanes(0)                                             # the product's own policy
+    toks, lens = ctx.transcribe_greedy(pcm, prompt, NEW, eot=-1)
+    assert toks.shape == (15, NEW) and np.all(lens == NEW)
+    assert len({r.tobytes() for r in toks}) == 15, "15 different recordings must give 15 different token rows"
+    for i in (0, 7, 8, 14):                                      # both groups, first and last row of each
+        alone, _ = ctx.transcribe_greedy(pcm[i:i + 1], prompt, NEW, eot=-1)
+        assert np.array_equal(alone[0], toks[i]), "chunk %d: its row inside the 15-chunk call differs from the chunk alone" % i
+    ctx.set_lanes(1)                                             # ... and the same call as ONE decode group of 15 rows
+    one, _ = ctx.transcribe_greedy(pcm, prompt, NEW, eot=-1)
+    ctx.set_lanes(0)
+    assert np.array_equal(one, toks)
+    sd = _oracle_weights(ctx, dims)
+    pick = [1, 8, 14]
+    mel = ctx.logmel(pcm[pick], n_mels=128)
+    xa = ctx.encode_mel(mel)
+    want = R.encode(sd, dims, mel).numpy()
+    assert gate("large_v3_shard.enc", R.rel_l2(xa, want), 6e-3)
+    worst = _check_greedy_against_teacher_forced_oracle(sd, dims, xa, prompt, toks[pick], scaled=True)
+    print("large-v3 full depth, 15-chunk shard on the product's lanes: worst greedy gap %.3g logit" % worst)
+    ctx.close()
+
+
 def test_bit_level_batch_invariance_at_d1280(pkg):
     """at d >= 1024 the round-1 kernels changed their summation order with the batch (split-K wave
     count, flash-decoding splits), so the same chunk could decode differently in groups of 1-4, 5-8 and > 8.  Round 2:
@@ -1525,6 +1564,59 @@ def test_flat_cross_attention_launch_shapes_are_bitwise_equal(pkg):
     lg1, lg3, lg16, gen, solo = outs[0]
     assert np.array_equal(lg1[0], lg16[0]) and np.array_equal(lg3, lg16[:3])
     assert np.array_equal(solo[0], gen[1]) and len({r.tobytes() for r in gen}) == 3
+
+
+def test_cross_attention_persistent_and_short_lived_shapes_are_bitwise_equal_under_load(pkg):
+    """which cross-attention launch shape a burst of positions gets (<= 256 persistent workgroups walking the
+    pairs, or one short-lived workgroup per pair) is decided at run time from what else decodes on the device, so bit-level
+    batch invariance needs the two shapes to give the same bits -- not just statistically.  tiny.en, a 48-row group
+    (288 pairs: persistent workgroups walk two pairs each), decoded (a) alone = persistent, (b) while a second context's
+    thread keeps decoding on the same device = short-lived (the process-wide counter), (c) under the same load with the
+    debug knob xattn_never_short = persistent under load.  A fresh context per case (a captured graph keeps its shape).
+    Greedy tokens of 64 positions: identical in all three."""
+    import ctypes
+    import threading
+    import time
+    dims = pkg.binding.MODEL_DIMS["tiny.en"]
+    lib = pkg.binding.load_debug_library()
+    lib.wmdbg_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    pcm = np.stack([tone_chunk(i) if i % 2 else L.synth_chunk(300 + i) for i in range(48)])
+    prompt = [50257, 50362]
+
+    def run(never_short, load):
+        lib.wmdbg_set_tuning(b"reset", 0)
+        assert lib.wmdbg_set_tuning(b"xattn_never_short", never_short) == 0
+        ctx = pkg.binding.Context(dims, debug=True)
+        ctx.init_synthetic(29, matrix_gain=LIVELY_GAIN)
+        _perturb_ln_on_device(ctx, dims, seed=6)
+        ctx.finalize()
+        ctx.set_lanes(1)
+        other = ctx.clone() if load else None
+        stop = threading.Event()
+
+        def churn():
+            other.set_lanes(1)
+            while not stop.is_set():
+                other.transcribe_greedy(pcm[:24], prompt, 64)
+        th = threading.Thread(target=churn) if load else None
+        try:
+            if th:
+                th.start()
+                time.sleep(0.2)                  # the other context's decode is in flight
+            return [ctx.transcribe_greedy(pcm, prompt, 64)[0] for _ in range(3)]
+        finally:
+            stop.set()
+            if th:
+                th.join()
+                other.close()
+            ctx.close()
+    try:
+        alone = run(0, False)
+        assert len({r.tobytes() for r in alone[0]}) >= 24
+        for t in alone[1:] + run(0, True) + run(1, True):
+            assert np.array_equal(t, alone[0])
+    finally:
+        lib.wmdbg_set_tuning(b"reset", 0)
 
 
 def _hip_free_bytes():

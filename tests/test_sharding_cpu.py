@@ -285,3 +285,16 @@ def test_c_abi_wav_reader_and_chunker(tmp_path):
             pkg.binding.Wav(p)
     with pytest.raises(pkg.binding.WhisperError, match="cannot open"):
         pkg.binding.Wav(os.path.join(tmp_path, "missing.wav"))
+
+
+def test_bench_refuses_a_launcher_whose_world_size_differs_from_gpus():
+    """bench.py --gpus N must never print a line whose n_gpus is not N: under a launcher that started another number of
+    ranks it stops before touching a GPU (this runs on the CPU box)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
+                       text=True, timeout=120, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and "--gpus 2" in r.stderr, (r.returncode, r.stderr[-500:])
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

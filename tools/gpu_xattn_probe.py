@@ -1,4 +1,5 @@
-"""GPU probe: cross-attention kernel variants (WM_XATTN_ROWS, WM_XATTN_WGS from the environment), alone and 2/3 concurrent."""
+"""GPU probe: the cross-attention kernel alone and 2 / 3 concurrent (launch-shape variants: wmdbg_set_tuning keys
+xattn_wgs / xattn_lds_pad / xattn_split_below through `bench.py --tuning`; the product reads no environment variable)."""
 import ctypes, sys, threading
 sys.path.insert(0, '.')
 import openai_whisper_coreml_amd as pkg
