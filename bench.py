@@ -232,7 +232,7 @@ def reference_flow_small(B, pcm16):
             lib.generate_spectrogram(buf.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
             xa = R.encode(sd, dims, out.astype(np.float32).reshape(1, 80, 3000))
             return R.detect_language(sd, dims, xa)
-        t_cpu, idx = _best_of(cpu_flow, 2)
+        t_cpu, (idx, _conf) = _best_of(cpu_flow, 2)
         res["cpu_oracle_ms"] = t_cpu * 1e3
         res["cpu_oracle_language_matches"] = bool(B.Whisper.LANGUAGES[int(np.asarray(idx).ravel()[0])] == lang)
         res["cpu_threads"] = torch.get_num_threads()
@@ -249,17 +249,25 @@ def frontend_alone(B, pcm16):
     x = pcm16[1].astype(np.float64) / 32768.0
     B.generateSpectrogram(x)                      # warm-up: context of the ABI symbol, tables
     t1, _ = _best_of(lambda: B.generateSpectrogram(x), 5)
-    n_thr, per = 8, 4
-    def worker():
+    n_thr, per = 8, 6
+
+    def worker(bar):
+        bar.wait()
         for _ in range(per):
             B.generateSpectrogram(x)
-    ths = [threading.Thread(target=worker) for _ in range(n_thr)]
-    t0 = time.perf_counter()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    t8 = time.perf_counter() - t0
+    t8 = None
+    for rep in range(3):   # first pass: the pool of front-end contexts behind the symbol is created (one per concurrent caller)
+        bar = threading.Barrier(n_thr + 1)
+        ths = [threading.Thread(target=worker, args=(bar,)) for _ in range(n_thr)]
+        for t in ths:
+            t.start()
+        bar.wait()
+        t0 = time.perf_counter()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        if rep > 0:
+            t8 = dt if t8 is None else min(t8, dt)
     return {"unit": "audio-sec/s", "value": 30.0 / t1, "one_caller_ms_per_chunk": t1 * 1e3,
             "eight_callers_audio_s_per_s": 30.0 * n_thr * per / t8,
             "what": "generate_spectrogram(double*, double*) through ctypes: 3.84 MB in + 1.92 MB out over PCIe per chunk "

@@ -614,8 +614,8 @@ struct AttnCold {
     const char *pf_ptr;
     long pf_tile_bytes;
 };
-template <int NS, int U, bool NT, bool DEEP = false>
-__global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_rows_attn_kernel(
+template <int NS, int U, bool NT, bool DEEP = false, int LB = (DEEP ? 256 : NS * 64)>
+__global__ __launch_bounds__(LB) void dec_rows_attn_kernel(
     const float *__restrict__ q, const bf16_t *__restrict__ kc, const bf16_t *__restrict__ vc,
     const int *__restrict__ pos_ptr, const int *__restrict__ live_rows /* [WM_DEC_MAXB] rows | [1] count, or null */,
     unsigned packA /* H | nsplit << 8 | flat_wpw << 16 */, unsigned packB /* T_stride | n_keys_const << 16 */,
@@ -1315,7 +1315,11 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
         // walk the pairs, balanced (56 chunks x 20 heads = 224 workgroups x 5 pairs).  Measured alone at B = 8 / 56 / 128:
         // 12.8 / 67 / 144 us (4.8 / 6.4 / 6.8 TB/s: ~6.4 is what HBM reads deliver).
         // short_lived (the chip is shared with other decode groups): one workgroup per pair, see WmModel::xattn_shared
-        const int cap = short_lived ? (1 << 30) : (g_wm_tuning.xattn_wgs > 0 ? g_wm_tuning.xattn_wgs : 256);
+        // alone on the device and at most two pairs per CU (a group of 13 .. 25 sequences at 20 heads): one workgroup per
+        // pair, TWO per CU (no LDS reservation) -- the persistent shape would put 300 pairs on 150 workgroups of two pairs
+        // each: 150 CUs, twelve dependent round trips per wave instead of six on all 256
+        const bool two_per_cu = !short_lived && B * H > 256 && B * H <= g_wm_tuning.xattn_pair_wg_max_pairs;
+        const int cap = (short_lived || two_per_cu) ? (1 << 30) : (g_wm_tuning.xattn_wgs > 0 ? g_wm_tuning.xattn_wgs : 256);
         int n_wg = B * H;
         if (n_wg > cap) {
             const int rounds = (n_wg + cap - 1) / cap;
@@ -1369,8 +1373,17 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
             const AttnCold cold = {att, part, (const char *)pf_ptr, tile_bytes};
             const unsigned pA = (unsigned)H | ((unsigned)nsplit << 8), pB = (unsigned)T_stride | ((unsigned)n_keys << 16);
             const unsigned pC = (unsigned)(B * H) | ((unsigned)n_wg << 16);
-            dec_rows_attn_kernel<8, 4, WM_XATTN_NT><<<grid, (8 / nsplit) * 64, nsplit == 1 ? lds_pad : 0, ctx->stream>>>(
-                q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
+            // LATENCY shape of the 8-wave kernel (round 5): fewer pairs than CUs (a batch of 5 .. 12 at 20 heads) and nothing
+            // else decoding on the device -- a workgroup owns ONE pair and its waves walk six blocks, one dependent memory
+            // round trip each (13.7 us for the 61 MB of a batch of 8: bytes in flight, not bandwidth).  Every block of every
+            // stream is requested up front instead (48 x 16 B per lane, ~250 VGPRs: one workgroup per CU either way); the
+            // block arithmetic and its order are the streaming kernel's: same bits.
+            if (nsplit == 1 && !short_lived && B * H <= g_wm_tuning.xattn_deep8_max_pairs && n_wg == B * H)
+                dec_rows_attn_kernel<8, 4, WM_XATTN_NT, true, 512><<<grid, 512, 0, ctx->stream>>>(
+                    q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
+            else
+                dec_rows_attn_kernel<8, 4, WM_XATTN_NT><<<grid, (8 / nsplit) * 64, (nsplit == 1 && !two_per_cu) ? lds_pad : 0, ctx->stream>>>(
+                    q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
         }
         WM_HIP(hipGetLastError());
     }

@@ -46,8 +46,11 @@ def main():
     if len(sys.argv) > 1:
         sets = [dict(kv.split("=") for kv in s.split(",") if kv) for s in sys.argv[1].split(";")]
     print("decode ms per position; columns: " + " | ".join(str(s) for s in sets))
-    for model, nb in (("tiny.en", 1), ("tiny.en", 8), ("base", 1), ("base", 8), ("small", 1), ("large-v2", 1), ("large-v2", 2),
-                      ("large-v2", 4), ("large-v2", 8)):
+    cfgs = (("tiny.en", 1), ("tiny.en", 8), ("base", 1), ("base", 8), ("small", 1), ("large-v2", 1), ("large-v2", 2),
+            ("large-v2", 4), ("large-v2", 8), ("large-v2", 12), ("large-v3", 15), ("large-v2", 24))
+    if len(sys.argv) > 2:   # model:batch,model:batch,...
+        cfgs = tuple((m, int(b)) for m, b in (c.split(":") for c in sys.argv[2].split(",")))
+    for model, nb in cfgs:
         row, ref = [], None
         for s in sets:
             ms, toks = run(model, nb, s)
