@@ -93,6 +93,56 @@ def build(force=False, verbose=True):
     return LIB
 
 
+ASAN_LIB = os.path.join(HERE, "libwhisper_mi355x_asan.so")
+
+
+def asan_runtime():
+    """The shared AddressSanitizer runtime of the ROCm clang (to be LD_PRELOADed into the python that loads ASAN_LIB)."""
+    r = subprocess.run([HIPCC, "--print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    p = r.stdout.strip()
+    if not os.path.isabs(p):   # hipcc wrapper: ask the clang it drives
+        import glob
+        c = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+        p = c[-1] if c else p
+    return p
+
+
+def build_sanitized(force=False, verbose=True):
+    """The SANITIZER LEG (README: `python openai-whisper-coreml_amd/build.py --asan`, then tools/run_sanitized.sh): the same
+    sources, HOST code instrumented with AddressSanitizer + UndefinedBehaviorSanitizer (device code untouched:
+    -fno-gpu-sanitize), into libwhisper_mi355x_asan.so -- product objects + the debug hooks, so that every C-ABI entry that
+    parses untrusted bytes (WAV, vocab.json, weight files, token payloads) and every host-side argument check runs under
+    the sanitizers, on the CPU box (front-end-free entries) and on the GPU box (everything)."""
+    obj_dir = os.path.join(HERE, "build_asan")
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = [f for f in FLAGS if f != "-O3"] + ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                                                "-fno-sanitize-recover=undefined", "-fno-gpu-sanitize", "-shared-libsan"]
+    hdr_t = _deps_mtime()
+
+    def comp(src):
+        obj = os.path.join(obj_dir, src + ".o")
+        sp = os.path.join(CSRC, src)
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) >= os.path.getmtime(sp) and os.path.getmtime(obj) >= hdr_t):
+            return obj
+        r = subprocess.run([HIPCC] + flags + FILE_FLAGS.get(src, []) + ["-x", "hip", "-c", sp, "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc (sanitized) failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        return obj
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(comp, sources()))
+    vmap = os.path.join(OBJ, "exports_debug.map")
+    if not os.path.exists(vmap):
+        build(verbose=False)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", ASAN_LIB] + objs + [
+        "-fsanitize=address,undefined", "-shared-libsan", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--version-script=" + vmap, "-lpthread", "-ldl"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link (sanitized) failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built", ASAN_LIB, "(LD_PRELOAD=%s)" % asan_runtime())
+    return ASAN_LIB
+
+
 def build_host(force=False, verbose=True, name="lid_main"):
     """C++ host harnesses (stand-ins for the Swift caller): lid_main = the reference's language-ID
     flow on one GPU, multi_main = all GPUs of the node from one dlopen-only process."""
@@ -114,6 +164,9 @@ def build_host(force=False, verbose=True, name="lid_main"):
 
 
 if __name__ == "__main__":
+    if "--asan" in sys.argv:
+        build_sanitized(force="--force" in sys.argv)
+        sys.exit(0)
     build(force="--force" in sys.argv)
     build_host(force="--force" in sys.argv)
     build_host(force="--force" in sys.argv, name="multi_main")

@@ -86,6 +86,7 @@ struct DecGemvDev {
     long pf_tile_bytes;    // bytes of one 16-row weight tile of that matrix
     int pf_tiles;
     int bgroups;           // workgroups per tile group along the batch: group g takes batch rows [g, g + 1) * NBLK * 16
+    int stagger;           // batch groups > 0 request their weights one round trip later (L2 hits instead of a second HBM stream)
 };
 
 // L2 warm-up workgroup: blockIdx >= n_tiles of the compute grid.  Workgroup n_tiles + t reads tile t of
@@ -152,8 +153,11 @@ struct GemvUnitOps {
     float2 sv[LN ? 20 : 1];  // statistics parts per lane group: d/16 <= 80 parts
 };
 
+// (r0, r1): the accumulator rows (of the lane's four) this wave will finish -- see "ROW SPLIT" in dec_gemv_kernel;
+// want_stats: this wave also forms the unit's LayerNorm statistics (one wave per unit)
 template <int EPI, bool LN>
-__device__ __forceinline__ void gemv_unit_load(const DecGemvDev &p, GemvUnitOps<EPI, LN> &o, int tile, int b0, int lane) {
+__device__ __forceinline__ void gemv_unit_load(const DecGemvDev &p, GemvUnitOps<EPI, LN> &o, int tile, int b0, int lane,
+                                               int r0 = 0, int r1 = 4, bool want_stats = true) {
     const int nrow = lane & 15, kq = lane >> 4;
     const int n = tile * 16 + nrow;
     const int nc = n < p.N ? n : p.N - 1;
@@ -171,16 +175,18 @@ __device__ __forceinline__ void gemv_unit_load(const DecGemvDev &p, GemvUnitOps<
     if (EPI == DE_RESID) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            if (r < r0 || r >= r1) continue;
             const int bl = kq * 4 + r;
             const int bc = b0 + (bl < nb ? bl : nb - 1);
             o.xold[r] = p.out_f32[(long)bc * p.ldo + nc];
             if (p.mean_in) o.off4[r] = p.mean_in[bc];
         }
     }
-    if (LN && p.mean_in) o.offrow = p.mean_in[b0 + (nrow < nb ? nrow : nb - 1)];
+    if (LN && p.mean_in && want_stats) o.offrow = p.mean_in[b0 + (nrow < nb ? nrow : nb - 1)];
     if (EPI == DE_LOGITS && p.ts.rng) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+            if (r < r0 || r >= r1) continue;
             const int bl = kq * 4 + r;
             o.trng[r] = *(const int4 *)(p.ts.rng + (long)(b0 + (bl < nb ? bl : nb - 1)) * 4);
         }
@@ -193,7 +199,7 @@ __device__ __forceinline__ void gemv_unit_load(const DecGemvDev &p, GemvUnitOps<
 #pragma unroll
         for (int u = 0; u < 20; ++u) {
             o.sv[u] = make_float2(0.f, 0.f);
-            if (u < nu) o.sv[u] = *(const float2 *)(sp + u * 128);
+            if (u < nu && want_stats) o.sv[u] = *(const float2 *)(sp + u * 128);
         }
     }
 }
@@ -228,13 +234,14 @@ __device__ __forceinline__ void gemv_unit_stats(const DecGemvDev &p, const GemvU
 template <int EPI, bool LN>
 __device__ __forceinline__ void gemv_unit_epilogue(const DecGemvDev &p, const GemvUnitOps<EPI, LN> &o, const f32x4 acc,
                                                    const float *st, int tile, int b0, int lane, int pos, unsigned mword0,
-                                                   unsigned mword1) {
+                                                   unsigned mword1, int r0 = 0, int r1 = 4) {
     const int nrow = lane & 15, kq = lane >> 4;
     const int n0 = tile * 16, n = n0 + nrow;
     const bool nvalid = n < p.N;
     const int nb = p.B - b0 < 16 ? p.B - b0 : 16;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+        if (r < r0 || r >= r1) continue;  // wave-uniform: this wave's share of the unit's rows
         const int bl = kq * 4 + r;
         const int b = b0 + bl;
         const bool bvalid = bl < nb;
@@ -391,7 +398,10 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
 #endif
         }
     };
-    load_wf(wave);
+    // (the workgroups of a tile group beyond the first -- batch groups 1 .. G-1, same XCD, dispatched right behind it --
+    // request their weights a memory round trip LATER, see below)
+    const bool late_w = grp > 0 && p.stagger != 0;
+    if (!late_w) load_wf(wave);
     // ... the activation fragments of its batch blocks: the activations are stored fragment-tiled exactly like the
     // weights (block of 16 rows x k-step = one contiguous KiB in MFMA A-operand order, written that way by their
     // producers), so this is ONE perfectly coalesced dwordx4 per lane per step too -- a row-major [B][K] buffer costs
@@ -420,17 +430,28 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
         GEMV_PIN(p.mask_first_pos); GEMV_PIN(p.ts.rng); GEMV_PIN(p.ts.key_ts); GEMV_PIN(p.ts.lse); GEMV_PIN(p.ts.ts_begin);
     }
     // ... and the epilogue operands of the (tile, block) unit this wave will finish: unit u = j * TN + t -> wave u % NW
+    // ROW SPLIT (round 5).  The epilogue of a (tile, block) unit used to be ONE wave's work while the workgroup's other
+    // waves had already finished: ~200 dependent instructions (shuffles for the statistics / arg-max keys, erf, scattered
+    // stores) at one wave's issue rate -- the out-projection (residual epilogue) took 0.9 us longer than the query
+    // projection on the same matrix.  When the workgroup has at least four waves per unit, a unit's four accumulator
+    // rows per lane (batch rows kq * 4 + r) are finished by FOUR waves, one r each: wave 4 u + r takes row r of unit u.
+    // Same instructions per element, same order of the split-K sum: same bits.
     int pos = 0;
     unsigned mword0 = 0u, mword1 = 0u;
     GemvUnitOps<EPI, LN> ops;
-    const bool has_unit = wave < NU;  // wave-uniform
+    const int RS = NU * 4 <= NW ? 4 : 1;        // waves per unit in the epilogue (workgroup-uniform)
+    const int ntask = NU * RS;
+    const bool has_unit = wave < ntask;         // wave-uniform: this wave finishes (part of) a unit
+    const int my_u = wave / RS;
+    const int my_r0 = RS == 4 ? (wave & 3) : 0, my_r1 = RS == 4 ? my_r0 + 1 : 4;
+    const bool my_stats = my_r0 == 0;           // the wave that forms the unit's LayerNorm statistics
     int utile = tile0, ub0 = bb;
     if (has_unit) {
-        utile = tile0 + wave % TN;
-        ub0 = bb + (wave / TN) * 16;
+        utile = tile0 + my_u % TN;
+        ub0 = bb + (my_u / TN) * 16;
         if (utile >= p.n_tiles) utile = p.n_tiles - 1;
         if (ub0 >= p.B) ub0 = bb;
-        gemv_unit_load<EPI, LN>(p, ops, utile, ub0, lane);
+        gemv_unit_load<EPI, LN>(p, ops, utile, ub0, lane, my_r0, my_r1, my_stats);
     }
     if (p.pos_ptr) pos = *p.pos_ptr;
     if (EPI == DE_LOGITS && p.mask && has_unit) {
@@ -438,6 +459,15 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
         const int nc = n < p.N ? n : p.N - 1;
         mword0 = p.mask[nc >> 5];
         mword1 = p.mask[p.mask_words + (nc >> 5)];
+    }
+    if (late_w) {
+        // STAGGERED WEIGHTS (round 5).  At 17 .. 128 rows a weight tile is read by G workgroups (one per
+        // NBLK batch blocks).  They start within ~100 ns of each other, all miss the XCD's L2 together and the tile crosses
+        // the fabric 1.45 - 1.6 times (PMC FETCH_SIZE, profiles/r04_pmc_fetch_size_group56.txt).  Workgroups 1 .. G-1 now
+        // wait for their activation / epilogue operands first (an L2 / Infinity-Cache round trip they need anyway) and ask
+        // for the weights afterwards: by then group 0's requests have filled the L2 and theirs are hits.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        load_wf(wave);
     }
 
     // ---- 2. products of this wave's K part(s): an activation fragment feeds the TN tiles
@@ -461,21 +491,26 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
                                                                  __builtin_bit_cast(bf16x8, wf[t][u]), a4, 0, 0, 0);
                 acc[j][t] = a4;
             }
-        if (PPW > 1 || NU > 1 || wave != 0) {  // (one part per wave, one unit: wave 0 finishes it from its own registers)
+        if (PPW > 1 || NU > 1 || wave != 0 || RS == 4) {  // (wave 0 alone finishing its own part needs no copy of it)
 #pragma unroll
             for (int j = 0; j < NBLK; ++j)
 #pragma unroll
                 for (int t = 0; t < TN; ++t) *(f32x4 *)(red + ((part * NU + j * TN + t) * 64 + lane) * 4) = acc[j][t];
         }
     }
-    if (has_unit) gemv_unit_stats<EPI, LN>(p, ops, st, lane, utile, ub0);
+    // the statistics slot of a unit: slot u when its rows are split over four waves (written by wave 4 u before the
+    // barrier, read by all four after it), else the finishing wave's own slot
+    float *stbase = red + NP * NU * 256;
+    if (has_unit && my_stats) gemv_unit_stats<EPI, LN>(p, ops, stbase + (RS == 4 ? my_u : wave) * 32, lane, utile, ub0);
     __syncthreads();
-    // ---- 4. fused epilogues: unit u on wave u % NW (first unit's operands are already here)
-    for (int u = wave; u < NU; u += NW) {  // wave-uniform
+    // ---- 4. fused epilogues: task t = (unit, row share) on wave t % NW (the first task's operands are already here)
+    for (int tk = wave; tk < ntask; tk += NW) {  // wave-uniform; RS == 4: at most one trip
+        const int u = tk / RS;
         const int t = u % TN, j = u / TN;
         const int tile = tile0 + t, b0 = bb + j * 16;
         if (tile >= p.n_tiles || b0 >= p.B) continue;
-        if (u != wave) {  // more units than waves (small models): operands fetched late
+        st = stbase + (RS == 4 ? u : wave) * 32;
+        if (tk != wave) {  // more units than waves (small models; RS == 1): operands fetched late
             gemv_unit_load<EPI, LN>(p, ops, tile, b0, lane);
             gemv_unit_stats<EPI, LN>(p, ops, st, lane, tile, b0);
             if (EPI == DE_LOGITS && p.mask) {
@@ -485,9 +520,9 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
                 mword1 = p.mask[p.mask_words + (nc >> 5)];
             }
         }
-        f32x4 sum = (NU == 1 && PPW == 1) ? acc[0][0] : *(const f32x4 *)(red + ((0 * NU + u) * 64 + lane) * 4);
+        f32x4 sum = (NU == 1 && PPW == 1 && wave == 0) ? acc[0][0] : *(const f32x4 *)(red + ((0 * NU + u) * 64 + lane) * 4);
         for (int w = 1; w < NP; ++w) sum += *(const f32x4 *)(red + ((w * NU + u) * 64 + lane) * 4);
-        gemv_unit_epilogue<EPI, LN>(p, ops, sum, st, tile, b0, lane, pos, mword0, mword1);
+        gemv_unit_epilogue<EPI, LN>(p, ops, sum, st, tile, b0, lane, pos, mword0, mword1, my_r0, my_r1);
     }
 }
 
@@ -1221,6 +1256,7 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     int tn = 1, nblk = 1;
     pick_shape(a.epi, ln, spw, nw, a.B, p.n_tiles, &tn, &nblk);
     p.bgroups = ((a.B + 15) / 16 + nblk - 1) / nblk;
+    p.stagger = g_wm_tuning.gemv_stagger;
     // the 16-part K = 4d residual product at more than one batch block: two parts per wave, 8-wave workgroups (two per
     // CU).  pick_shape keeps every 16-wave split at one (tile, block) unit per workgroup, which is what the two-part
     // kernel is built for (d = 768 / 1024 / 1280: spw = 6 / 8 / 10).
@@ -1315,9 +1351,10 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
         // walk the pairs, balanced (56 chunks x 20 heads = 224 workgroups x 5 pairs).  Measured alone at B = 8 / 56 / 128:
         // 12.8 / 67 / 144 us (4.8 / 6.4 / 6.8 TB/s: ~6.4 is what HBM reads deliver).
         // short_lived (the chip is shared with other decode groups): one workgroup per pair, see WmModel::xattn_shared
-        // alone on the device and at most two pairs per CU (a group of 13 .. 25 sequences at 20 heads): one workgroup per
-        // pair, TWO per CU (no LDS reservation) -- the persistent shape would put 300 pairs on 150 workgroups of two pairs
-        // each: 150 CUs, twelve dependent round trips per wave instead of six on all 256
+        // EXPERIMENT, off in the product (xattn_pair_wg_max_pairs = 0): alone on the device and at most two pairs per CU (a
+        // group of 13 .. 25 sequences at 20 heads): one workgroup per pair, TWO per CU (no LDS reservation) instead of the
+        // persistent shape's 150 workgroups of two pairs each.  Measured: SLOWER (large-v3 x 15: 2.123 vs 2.042 ms per
+        // position; large-v2 x 16: 2.097 vs 2.022): sixteen streaming waves per CU do worse than eight
         const bool two_per_cu = !short_lived && B * H > 256 && B * H <= g_wm_tuning.xattn_pair_wg_max_pairs;
         const int cap = (short_lived || two_per_cu) ? (1 << 30) : (g_wm_tuning.xattn_wgs > 0 ? g_wm_tuning.xattn_wgs : 256);
         int n_wg = B * H;
@@ -1373,11 +1410,12 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
             const AttnCold cold = {att, part, (const char *)pf_ptr, tile_bytes};
             const unsigned pA = (unsigned)H | ((unsigned)nsplit << 8), pB = (unsigned)T_stride | ((unsigned)n_keys << 16);
             const unsigned pC = (unsigned)(B * H) | ((unsigned)n_wg << 16);
-            // LATENCY shape of the 8-wave kernel (round 5): fewer pairs than CUs (a batch of 5 .. 12 at 20 heads) and nothing
-            // else decoding on the device -- a workgroup owns ONE pair and its waves walk six blocks, one dependent memory
-            // round trip each (13.7 us for the 61 MB of a batch of 8: bytes in flight, not bandwidth).  Every block of every
-            // stream is requested up front instead (48 x 16 B per lane, ~250 VGPRs: one workgroup per CU either way); the
-            // block arithmetic and its order are the streaming kernel's: same bits.
+            // EXPERIMENT, off in the product (xattn_deep8_max_pairs = 0): fewer pairs than CUs (a batch of 5 .. 12 at 20
+            // heads) -- a workgroup owns ONE pair and its waves walk six blocks, one dependent memory round trip each, so
+            // every block of every stream requested up front (48 x 16 B per lane, 256 VGPRs) should have been the latency
+            // shape.  Measured: SLOWER -- 16.1 vs 13.8 us at 8 sequences, 1.764 vs 1.626 ms per position (large-v2), 0.212 vs
+            // 0.201 at tiny.en x 24: the stream is not short of bytes in flight; 8 waves x 48 requests per CU queue in front
+            // of the CU's own memory pipeline.  Same bits (the launch-shape tests run it through the debug knob).
             if (nsplit == 1 && !short_lived && B * H <= g_wm_tuning.xattn_deep8_max_pairs && n_wg == B * H)
                 dec_rows_attn_kernel<8, 4, WM_XATTN_NT, true, 512><<<grid, 512, 0, ctx->stream>>>(
                     q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);

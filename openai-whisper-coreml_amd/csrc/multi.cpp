@@ -102,6 +102,8 @@ extern "C" int wm_multi_pack_tokens(const int32_t *tokens, const int32_t *lens, 
     WM_REQUIRE((uint64_t)per * (1 + (uint64_t)max_new) <= (uint64_t)1 << 40, WM_ERR_INVALID, "pack_tokens: payload too large");
     const size_t stride = 1 + (size_t)max_new;
     memset(payload, 0, (size_t)per * stride * sizeof(int32_t));
+    for (int i = 0; i < n_local; ++i)
+        WM_REQUIRE(lens[i] >= 0 && lens[i] <= max_new, WM_ERR_INVALID, "pack_tokens: length %d of chunk %d outside [0, %d]", lens[i], i, max_new);
     for (int i = 0; i < n_local; ++i) {
         payload[i * stride] = lens[i];
         memcpy(payload + i * stride + 1, tokens + (size_t)i * max_new, (size_t)max_new * sizeof(int32_t));
@@ -116,6 +118,11 @@ extern "C" int wm_multi_unpack_tokens(const int32_t *gathered, int world_size, i
     WM_REQUIRE((uint64_t)world_size * (uint64_t)per * (1 + (uint64_t)max_new) <= (uint64_t)1 << 40, WM_ERR_INVALID,
                "unpack_tokens: payload too large");
     const size_t stride = 1 + (size_t)max_new;
+    // the payload was written by OTHER ranks: a length outside [0, max_new] is a corrupt exchange, not something to hand to
+    // a caller who will index tokens_out with it (fuzz test: tests/test_fuzz_cpu.py)
+    for (size_t c = 0; c < (size_t)n_chunks; ++c)
+        WM_REQUIRE(gathered[c * stride] >= 0 && gathered[c * stride] <= max_new, WM_ERR_INVALID,
+                   "unpack_tokens: chunk %zu carries length %d outside [0, %d]: corrupt token payload", c, gathered[c * stride], max_new);
     for (size_t c = 0; c < (size_t)n_chunks; ++c) {  // rank r's block starts at row r * per of the gathered buffer == chunk r * per
         lens_out[c] = gathered[c * stride];
         memcpy(tokens_out + c * (size_t)max_new, gathered + c * stride + 1, (size_t)max_new * sizeof(int32_t));

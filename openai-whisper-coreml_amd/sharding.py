@@ -51,6 +51,8 @@ def gather_tokens(dist, tokens, lens, n_chunks, world_size, device=None):
     out = [torch.empty_like(t) for _ in range(world_size)]
     dist.all_gather(out, t)
     allb = torch.cat([o.cpu() for o in out], dim=0).numpy()[:n_chunks]
+    if allb.size and (allb[:, 0].min() < 0 or allb[:, 0].max() > max_new):   # written by other ranks (wm_multi_unpack_tokens)
+        raise ValueError("gather_tokens: a rank sent a length outside [0, %d]: corrupt token payload" % max_new)
     return allb[:, 1:].copy(), allb[:, 0].copy()
 
 

@@ -9,9 +9,11 @@ repo's own restatements (oracle/).  This script records the REFERENCE's outputs 
 use, as small fixtures under tests/golden/; tests/test_reference_goldens.py picks them up automatically (it is skipped
 while they do not exist) and pins the oracle -- and through it the HIP path -- to the reference itself.
 
-    # front end (needs cargo and network access for the crates):
+    # front end (needs cargo and network access for the crates; ~1 min: a release build of 5 small crates, ~60 MB of cargo
+    # target directory in $TMPDIR, a 150 KB fixture; prints the oracle-vs-crate difference it just observed):
     python tests/golden/dump_reference_goldens.py --stft-crate /path/to/OpenAI-Whisper-CoreML/stft
-    # model (needs `pip install openai-whisper`; downloads "small" exactly as whisper_to_cml.py:7 does):
+    # model (needs `pip install openai-whisper`; downloads "small" exactly as whisper_to_cml.py:7 does: 461 MB once, then
+    # ~20 s of CPU; a 1 MB fixture; prints the oracle-vs-openai-whisper difference on the checkpoint's own weights):
     python tests/golden/dump_reference_goldens.py --whisper-model small
 
 Nothing here is product code, and nothing of the reference's sources is copied: the crate is built where it lies (as a
@@ -56,6 +58,33 @@ def dump_stft(crate_dir):
     path = os.path.join(HERE, "ref_stft_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path)
+    compare_with_oracle(out, "the Rust crate")
+
+
+def compare_with_oracle(ref, who):
+    """The comparison the pinned tests will make, printed on the spot: the reference's outputs just recorded against this
+    repo's C restatement (oracle/logmel_ref.c, built on demand with gcc) on the same seeded inputs.  What to expect: two f64
+    implementations of lib.rs:22-122 that differ only in the FFT (realfft's mixed-radix 400-point plan vs a direct DFT)
+    agree to ~1e-12 on the log-mel values and bit for bit on the reflect pads; tests/test_reference_goldens.py gates 1e-9."""
+    so = os.path.join(ROOT, "oracle", "liboracle_logmel.so")
+    if not os.path.exists(so):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    mine = stft_fixture(ctypes.CDLL(so), "oracle/logmel_ref.c")
+    worst = 0.0
+    print("oracle (oracle/logmel_ref.c) vs %s, same seeded inputs:" % who)
+    for key in sorted(k for k in ref if k.endswith("_cols")):
+        case = key[:-5]
+        d_cols = float(np.abs(np.asarray(ref[key]) - mine[key]).max())
+        d_sum = float(np.abs(np.asarray(ref[case + "_sum"]) - mine[case + "_sum"]).max())
+        pads = bool(np.array_equal(ref[case + "_pad_head"], mine[case + "_pad_head"]) and
+                    np.array_equal(ref[case + "_pad_tail"], mine[case + "_pad_tail"]))
+        worst = max(worst, d_cols)
+        print("  %-7s max |log-mel diff| over %d sampled frames x 80 bins: %.3e   checksum diff: %.3e   reflect pads bit-equal: %s"
+              % (case, len(ref["frames"]), d_cols, d_sum, pads))
+    print("  worst %.3e -- %s (gate of tests/test_reference_goldens.py: 1e-9).  Now commit tests/golden/ref_stft_golden.npz: "
+          "`pytest tests/test_reference_goldens.py` stops skipping and pins the oracle, and through it the HIP path (-m gpu), "
+          "to the reference itself." % (worst, "PINNED" if worst <= 1e-9 else "ABOVE THE GATE: the restatement differs from the crate"))
+    return worst
 
 
 def stft_fixture(lib, source):
@@ -103,6 +132,15 @@ def dump_whisper(name):
     out = model_fixture(name, dims, h.hexdigest(), mel[0].numpy(), xa.numpy(), toks.numpy(), logits.numpy())
     path = os.path.join(HERE, "ref_whisper_%s_golden.npz" % name.replace(".", "_"))
     np.savez_compressed(path, **out)
+    try:   # the same on-the-spot comparison for the model half: the oracle (oracle/whisper_ref.py) on the checkpoint's own weights
+        from oracle import whisper_ref as R
+        sd_np = {k: v.cpu().float().numpy() for k, v in sd.items()}
+        o_xa = R.encode(R.to_torch(sd_np), dims, mel.numpy()).numpy()
+        o_lg = R.decode_logits(R.to_torch(sd_np), dims, toks.numpy().astype(np.int32), o_xa).numpy()
+        print("oracle (oracle/whisper_ref.py) vs openai-whisper %s: encoder rel-L2 %.3e, logits rel-L2 %.3e (gates of "
+              "tests/test_reference_goldens.py: 1e-4)" % (name, R.rel_l2(o_xa, xa.numpy()), R.rel_l2(o_lg, logits.numpy())))
+    except Exception as e:   # the fixture is what matters; the comparison is a convenience
+        print("on-the-spot oracle comparison skipped:", repr(e))
     print("wrote", path, "-- convert the same checkpoint with openai-whisper-coreml_amd/weights.py:convert_openai_pt and set "
           "WM_REF_WEIGHTS=<flat file> so that tests/test_reference_goldens.py can load it")
 
