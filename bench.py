@@ -134,9 +134,12 @@ def other_configs(B, main_model, pcm16, max_new=224):
     inside the library) and the stage rooflines."""
     out = {}
     # (key, model, chunks, repetitions, lanes): lanes 1 = ONE decode group on one lane; lanes 0 = the product's own policy
-    # (wm_transcribe_greedy splits the call into decode groups over $WM_LANES weight-sharing lanes: 15 chunks -> 8 + 7)
+    # (round 5, measured: one group below 32 chunks, two groups up to 143, three from 144; rounds 1-4 cut 15 chunks into 8 + 7
+    # on two lanes, which is what lanes = 3 -- an explicit lane count -- still does: reported beside it)
     cases = [("tiny.en_b1_latency", "tiny.en", 1, 3, 1), ("base_b32_one_group", "base", 32, 2, 1),
-             ("large-v3_15_chunks_one_group", "large-v3", 15, 2, 1), ("large-v3_15_chunks_product_lanes", "large-v3", 15, 2, 0)]
+             ("base_b32_product_policy", "base", 32, 2, 0),
+             ("large-v3_15_chunks_one_group", "large-v3", 15, 2, 1), ("large-v3_15_chunks_product_policy", "large-v3", 15, 2, 0),
+             ("large-v3_15_chunks_three_lanes", "large-v3", 15, 2, 3)]
     ctx_cache = {}
     for key, model, nb, reps, lanes in cases:
         try:
@@ -166,7 +169,8 @@ def other_configs(B, main_model, pcm16, max_new=224):
                         "distinct_token_rows": len({r.tobytes() for r in toks}),
                         "timing": "min of %d calls after one warm-up call, %s" % (
                             reps, "one decode group on one lane" if lanes == 1 else
-                            "the product's own group / lane policy (wm_transcribe_greedy default)")}
+                            "the product's own group / lane policy (wm_transcribe_greedy default)" if lanes == 0 else
+                            "wm_set_lanes(%d): groups of ~8 chunks on weight-sharing lanes (the rounds-1-4 rule)" % lanes)}
             if lanes == 1:   # per-stage figures only mean something for ONE group (lanes overlap their stages)
                 out[key].update({
                     "decode_stage_tok_per_s": nb * max_new / max(stage[2], 1e-9),
@@ -174,13 +178,15 @@ def other_configs(B, main_model, pcm16, max_new=224):
                     "stage_ms": {"frontend": stage[0] * 1e3, "encoder_xkv": stage[1] * 1e3, "decode": stage[2] * 1e3},
                     "stage_roofline": stage_rooflines(dims, nb, len(prompt), max_new, 1.0, stage)})
             else:
-                out[key]["tokens_equal_one_group_run"] = bool(np.array_equal(toks, out.get("large-v3_15_chunks_one_group_tokens", toks)))
-            if key == "large-v3_15_chunks_one_group":
-                out["large-v3_15_chunks_one_group_tokens"] = toks
+                ref_t = out.get("_tokens_" + model)
+                out[key]["tokens_equal_one_group_run"] = None if ref_t is None else bool(np.array_equal(toks, ref_t))
+            if lanes == 1:
+                out["_tokens_" + model] = toks
             c.dev_free(dp)
         except Exception as e:   # never take the headline down
             out[key] = {"model": model, "chunks": nb, "value": None, "error": repr(e)}
-    out.pop("large-v3_15_chunks_one_group_tokens", None)
+    for k_ in [k_ for k_ in out if k_.startswith("_tokens_")]:
+        out.pop(k_)
     for o in ctx_cache.values():
         o.close()
     for name, fn in (("small_lid_reference_flow", reference_flow_small), ("frontend_reference_abi", frontend_alone)):

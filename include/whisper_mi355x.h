@@ -170,9 +170,14 @@ WM_API int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype
                          const int32_t *prompt, int n_prompt, int max_new, int32_t eot,
                          int32_t *tokens_out, int32_t *lens_out, wm_mem mem);
 
-/* Decode groups a wm_transcribe_greedy call on this context keeps in flight (1 .. 8 lanes; 0 = the default, $WM_LANES
- * or 3).  1: the whole call (up to 128 chunks) is ONE decode group on the context's own stream -- what a host that runs
- * its own concurrency over wm_clone'd contexts wants (bench.py), and what a test of one large group needs. */
+/* Decode groups a wm_transcribe_greedy call on this context keeps in flight.
+ *   0 (default): the library's own measured policy -- one group below 32 chunks, two groups (two weight-sharing lanes)
+ *                up to 143, three from 144 chunks, never more than $WM_LANES (default 3) at once;
+ *   1          : the whole call (up to 128 chunks) is ONE decode group on the context's own stream -- what a host that runs
+ *                its own concurrency over wm_clone'd contexts wants (bench.py);
+ *   n = 2 .. 8 : n groups in flight whenever the call has 8 chunks for each (groups of ~8 up to 8 n chunks, n balanced
+ *                groups of up to 128 beyond): a host that knows its latency / throughput trade-off better than the default.
+ * Tokens do not depend on the choice (bit-level batch invariance). */
 WM_API int wm_set_lanes(wm_ctx *ctx, int n_lanes);
 
 /* Logit filters of openai-whisper's greedy decode() (whisper/decoding.py SuppressTokens and SuppressBlank; SURVEY.md 8f

@@ -86,7 +86,6 @@ struct DecGemvDev {
     long pf_tile_bytes;    // bytes of one 16-row weight tile of that matrix
     int pf_tiles;
     int bgroups;           // workgroups per tile group along the batch: group g takes batch rows [g, g + 1) * NBLK * 16
-    int stagger;           // batch groups > 0 request their weights one round trip later (L2 hits instead of a second HBM stream)
 };
 
 // L2 warm-up workgroup: blockIdx >= n_tiles of the compute grid.  Workgroup n_tiles + t reads tile t of
@@ -398,10 +397,7 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
 #endif
         }
     };
-    // (the workgroups of a tile group beyond the first -- batch groups 1 .. G-1, same XCD, dispatched right behind it --
-    // request their weights a memory round trip LATER, see below)
-    const bool late_w = grp > 0 && p.stagger != 0;
-    if (!late_w) load_wf(wave);
+    load_wf(wave);
     // ... the activation fragments of its batch blocks: the activations are stored fragment-tiled exactly like the
     // weights (block of 16 rows x k-step = one contiguous KiB in MFMA A-operand order, written that way by their
     // producers), so this is ONE perfectly coalesced dwordx4 per lane per step too -- a row-major [B][K] buffer costs
@@ -459,15 +455,6 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
         const int nc = n < p.N ? n : p.N - 1;
         mword0 = p.mask[nc >> 5];
         mword1 = p.mask[p.mask_words + (nc >> 5)];
-    }
-    if (late_w) {
-        // STAGGERED WEIGHTS (round 5).  At 17 .. 128 rows a weight tile is read by G workgroups (one per
-        // NBLK batch blocks).  They start within ~100 ns of each other, all miss the XCD's L2 together and the tile crosses
-        // the fabric 1.45 - 1.6 times (PMC FETCH_SIZE, profiles/r04_pmc_fetch_size_group56.txt).  Workgroups 1 .. G-1 now
-        // wait for their activation / epilogue operands first (an L2 / Infinity-Cache round trip they need anyway) and ask
-        // for the weights afterwards: by then group 0's requests have filled the L2 and theirs are hits.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        load_wf(wave);
     }
 
     // ---- 2. products of this wave's K part(s): an activation fragment feeds the TN tiles
@@ -1256,7 +1243,6 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     int tn = 1, nblk = 1;
     pick_shape(a.epi, ln, spw, nw, a.B, p.n_tiles, &tn, &nblk);
     p.bgroups = ((a.B + 15) / 16 + nblk - 1) / nblk;
-    p.stagger = g_wm_tuning.gemv_stagger;
     // the 16-part K = 4d residual product at more than one batch block: two parts per wave, 8-wave workgroups (two per
     // CU).  pick_shape keeps every 16-wave split at one (tile, block) unit per workgroup, which is what the two-part
     // kernel is built for (d = 768 / 1024 / 1280: spw = 6 / 8 / 10).

@@ -562,10 +562,22 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
     stop.budgets = budgets.empty() ? nullptr : budgets.data();
     // Split the B chunks into G balanced decode groups (<= WM_DEC_MAXB each, kGroupChunks preferred) and run
     // them on L lanes.  Per-kernel profiling keeps everything on the caller's context (one lane).
-    const int L = ctx->prof.on ? 1 : (ctx->max_lanes > 0 ? ctx->max_lanes : lane_limit());
+    // GROUP POLICY (round 5, measured: profiles/r05_group_policy.txt).  Rounds 1-4 cut every call into groups of ~8 chunks
+    // on up to three lanes.  At large-v2 that is the WORST choice below ~50 chunks (15 chunks: 8 + 7 on two lanes 826
+    // audio-s/s, one group of 15 860; 48 chunks: 3 x 16 1449, one group 1538): a group's weight stream is shared by all its
+    // rows, and two latency-bound chains on two hardware queues do not overlap for free.  Two groups start to pay once each
+    // is big enough to be bandwidth-bound (64: 2 x 32 1697 vs 1661; 96: 2 x 48 1946 vs 1860; 128: 2 x 64 2019 vs 1896), three
+    // from ~150 (160: 3 x 53 = 2 x 80).  A small model wants the second group earlier (base, 32 chunks: 2 x 16 +10 %), hence
+    // the threshold of 32.  A host that SETS a lane count (wm_set_lanes n > 1) asks for n groups in flight whenever there are
+    // 8 chunks for each -- the rounds-1-4 rule, and what keeps the lanes under test at small sizes.
+    const bool explicit_lanes = ctx->max_lanes > 0;
+    const int L = ctx->prof.on ? 1 : (explicit_lanes ? ctx->max_lanes : lane_limit());
     int G;
     const int gc = g_wm_tuning.group_chunks > 0 ? g_wm_tuning.group_chunks : kGroupChunks;   // (probes only; 0 in the product)
-    if (B <= gc * L) {
+    if (!explicit_lanes && g_wm_tuning.group_chunks == 0 && B < 144) {
+        G = B < 32 ? 1 : 2;
+        if (G > L) G = L;
+    } else if (B <= gc * L) {
         G = (B + gc - 1) / gc;
     } else {
         G = (B + WM_DEC_MAXB - 1) / WM_DEC_MAXB;

@@ -175,7 +175,6 @@ struct WmTuning {
     int xattn_no_deep = 0;        // 1: the flat (few-pair) cross-attention walks its blocks one round trip at a time
     int xattn_deep8_max_pairs = 0;    // EXPERIMENT (lost, profiles/r05_latency_probe.txt): 8-wave cross-attention with every block requested up front up to this many pairs
     int xattn_pair_wg_max_pairs = 0;  // EXPERIMENT (lost, same file): alone, 257 .. this many pairs: one cross-attention workgroup per pair, two per CU
-    int gemv_stagger = 1;         // decode GEMV: workgroups of a tile beyond the first request the weights after their activations (0: all at once)
     int group_chunks = 0;         // preferred decode-group size of a wm_transcribe_greedy call (product rule: model_api.cpp)
 };
 extern WmTuning g_wm_tuning;   // api.cpp
