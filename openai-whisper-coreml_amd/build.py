@@ -107,16 +107,24 @@ def asan_runtime():
     return p
 
 
-def build_sanitized(force=False, verbose=True):
+UBSAN_LIB = os.path.join(HERE, "libwhisper_mi355x_ubsan.so")
+
+
+def build_sanitized(force=False, verbose=True, kind="asan"):
     """The SANITIZER LEG (README: `python openai-whisper-coreml_amd/build.py --asan`, then tools/run_sanitized.sh): the same
     sources, HOST code instrumented with AddressSanitizer + UndefinedBehaviorSanitizer (device code untouched:
     -fno-gpu-sanitize), into libwhisper_mi355x_asan.so -- product objects + the debug hooks, so that every C-ABI entry that
     parses untrusted bytes (WAV, vocab.json, weight files, token payloads) and every host-side argument check runs under
     the sanitizers, on the CPU box (front-end-free entries) and on the GPU box (everything)."""
-    obj_dir = os.path.join(HERE, "build_asan")
+    # kind "ubsan": UndefinedBehaviorSanitizer only -- the flavour that can run NEXT TO THE HIP RUNTIME.  (Measured on the GPU
+    # box: under the AddressSanitizer runtime hipInit aborts -- the HSA runtime's address-space reservation collides with
+    # ASan's shadow memory and this image ships no ASan build of ROCm -- so the GPU leg is UBSan + the guard-band canaries of
+    # tests/test_canary_gpu.py, the CPU leg ASan + UBSan.)
+    san = "address,undefined" if kind == "asan" else "undefined,bounds,float-cast-overflow"
+    obj_dir = os.path.join(HERE, "build_" + kind)
     os.makedirs(obj_dir, exist_ok=True)
-    flags = [f for f in FLAGS if f != "-O3"] + ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
-                                                "-fno-sanitize-recover=undefined", "-fno-gpu-sanitize", "-shared-libsan"]
+    flags = [f for f in FLAGS if f != "-O3"] + ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=" + san,
+                                                "-fno-sanitize-recover=all", "-fno-gpu-sanitize", "-shared-libsan"]
     hdr_t = _deps_mtime()
 
     def comp(src):
@@ -133,14 +141,16 @@ def build_sanitized(force=False, verbose=True):
     vmap = os.path.join(OBJ, "exports_debug.map")
     if not os.path.exists(vmap):
         build(verbose=False)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", ASAN_LIB] + objs + [
-        "-fsanitize=address,undefined", "-shared-libsan", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--version-script=" + vmap, "-lpthread", "-ldl"]
+    out = ASAN_LIB if kind == "asan" else UBSAN_LIB
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + [
+        "-fsanitize=" + san, "-shared-libsan", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath," + os.path.dirname(asan_runtime()),
+        "-Wl,--version-script=" + vmap, "-lpthread", "-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link (sanitized) failed:\n%s\n%s" % (r.stdout, r.stderr))
     if verbose:
-        print("built", ASAN_LIB, "(LD_PRELOAD=%s)" % asan_runtime())
-    return ASAN_LIB
+        print("built", out, "(LD_PRELOAD=%s)" % asan_runtime() if kind == "asan" else "(no preload needed)")
+    return out
 
 
 def build_host(force=False, verbose=True, name="lid_main"):
@@ -164,8 +174,8 @@ def build_host(force=False, verbose=True, name="lid_main"):
 
 
 if __name__ == "__main__":
-    if "--asan" in sys.argv:
-        build_sanitized(force="--force" in sys.argv)
+    if "--asan" in sys.argv or "--ubsan" in sys.argv:
+        build_sanitized(force="--force" in sys.argv, kind="asan" if "--asan" in sys.argv else "ubsan")
         sys.exit(0)
     build(force="--force" in sys.argv)
     build_host(force="--force" in sys.argv)

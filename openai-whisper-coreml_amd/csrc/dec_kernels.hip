@@ -478,7 +478,7 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
                                                                  __builtin_bit_cast(bf16x8, wf[t][u]), a4, 0, 0, 0);
                 acc[j][t] = a4;
             }
-        if (PPW > 1 || NU > 1 || wave != 0 || RS == 4) {  // (wave 0 alone finishing its own part needs no copy of it)
+        {   // (every wave's part goes through LDS: with the rows of a unit split over four waves nobody finishes alone)
 #pragma unroll
             for (int j = 0; j < NBLK; ++j)
 #pragma unroll
@@ -507,8 +507,18 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
                 mword1 = p.mask[p.mask_words + (nc >> 5)];
             }
         }
-        f32x4 sum = (NU == 1 && PPW == 1 && wave == 0) ? acc[0][0] : *(const f32x4 *)(red + ((0 * NU + u) * 64 + lane) * 4);
-        for (int w = 1; w < NP; ++w) sum += *(const f32x4 *)(red + ((w * NU + u) * 64 + lane) * 4);
+        f32x4 sum;
+        if (RS == 4) {
+            // this wave finishes ONE accumulator row of the unit: it reads that component only (eight waves reading whole
+            // f32x4 partials were 4 x the LDS traffic of the two-wave epilogue and cost the LayerNorm GEMVs 0.3 - 0.5 us)
+            const float *rp = red + (u * 64 + lane) * 4 + my_r0;
+            float s1 = rp[0];
+            for (int w = 1; w < NP; ++w) s1 += rp[w * NU * 256];
+            sum = f32x4{s1, s1, s1, s1};  // (the epilogue looks at component my_r0 only)
+        } else {
+            sum = *(const f32x4 *)(red + ((0 * NU + u) * 64 + lane) * 4);
+            for (int w = 1; w < NP; ++w) sum += *(const f32x4 *)(red + ((w * NU + u) * 64 + lane) * 4);
+        }
         gemv_unit_epilogue<EPI, LN>(p, ops, sum, st, tile, b0, lane, pos, mword0, mword1, my_r0, my_r1);
     }
 }
@@ -992,7 +1002,23 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
         for (int b = bw + wave; b < B && b < bw + 16; b += 16) {
             const long tok = tok_s[b - bw];
             float s1 = 0.f, s2 = 0.f;
-            for (int j = lane; j < d; j += 64) {
+            // the row stays in registers between the sums and the mean-centred bf16 copy (the first 512 columns: 8 values per lane; the
+            // round-4 kernel re-read what it had just stored: a store -> load round trip through L2 on the step's tail)
+            constexpr int EV = 8;   // (d <= 512 entirely: tiny, base -- where a step is 35 launches and this trip is 0.5 % of it)
+            float ev[EV];
+#pragma unroll
+            for (int i = 0; i < EV; ++i) {
+                const int j = lane + 64 * i;
+                ev[i] = 0.f;
+                if (j < d) {
+                    const float v = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)(pos + 1) * d + j];
+                    x[(long)b * d + j] = v;
+                    ev[i] = v;
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+            for (int j = lane + 64 * EV; j < d; j += 64) {  // (wider models than any Whisper: the re-reading path)
                 const float v = bf2f(emb[wm_tiled_offset((size_t)tok, (size_t)j, (size_t)d)]) + pemb[(long)(pos + 1) * d + j];
                 x[(long)b * d + j] = v;
                 s1 += v;
@@ -1003,9 +1029,14 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
                 s1 += __shfl_xor(s1, o);
                 s2 += __shfl_xor(s2, o);
             }
-            {   // bf16 copy, mean-centred (see DecGemvDev::mean_in); each lane re-reads the elements it just wrote
+            {   // bf16 copy, mean-centred (see DecGemvDev::mean_in)
                 const float mean = s1 / (float)d;
-                for (int j = lane; j < d; j += 64)
+#pragma unroll
+                for (int i = 0; i < EV; ++i) {
+                    const int j = lane + 64 * i;
+                    if (j < d) xb[wm_tiled_offset((size_t)b, (size_t)j, (size_t)d)] = f2bf(ev[i] - mean);
+                }
+                for (int j = lane + 64 * EV; j < d; j += 64)
                     xb[wm_tiled_offset((size_t)b, (size_t)j, (size_t)d)] = f2bf(x[(long)b * d + j] - mean);
                 if (lane == 0 && mean_buf) mean_buf[b] = mean;
             }

@@ -1429,7 +1429,14 @@ def test_early_stop_decode_time_follows_the_longest_live_sequence(pkg):
     assert np.all(l_short == 20) and np.array_equal(short[:, :20], full[:, :20])
     assert l_strag.tolist() == [20] * (n - 1) + [NEW] and np.array_equal(strag[-1], full[-1])
     assert t_short <= 0.25 * t_full, (t_short, t_full)          # 23 positions (+ <= 2 bursts of slack) instead of 203
-    assert t_strag <= 0.80 * t_full, (t_strag, t_full)          # weights still stream, 23 of 24 cache streams do not
+    # weights still stream, 23 of 24 cache streams do not.  (Round 5: the 24 chunks are ONE decode group now -- measured
+    # 0.81 of the full decode; rounds 3-4 cut them into three groups of 8, two of which ended after 20 tokens: 0.6 - 0.7)
+    assert t_strag <= 0.88 * t_full, (t_strag, t_full)
+    ctx.set_lanes(3)                                            # the rounds-3-4 split: finished GROUPS are not decoded further
+    t_strag3, strag3, _ = run([20] * (n - 1) + [NEW])
+    ctx.set_lanes(0)
+    print("one straggler, three groups of 8: %.1f ms" % t_strag3)
+    assert np.array_equal(strag3, strag)
     ctx.dev_free(dp)
     ctx.close()
 

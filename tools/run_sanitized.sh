@@ -2,8 +2,8 @@
 # The SANITIZER LEG (README "Sanitizers"): host code of the whole library under AddressSanitizer + UBSan.
 #   tools/run_sanitized.sh          CPU box: every test that reaches the library without a GPU (ABI loading, WAV reader,
 #                                   de-tokenizer, token payloads, partition) + the hypothesis fuzz tests with more examples
-#   tools/run_sanitized.sh gpu      GPU box: additionally the canary / malformed-weight-file / WAV-to-tokens / host-harness
-#                                   GPU tests (every caller-owned output buffer, every host-pointer entry)
+#   tools/run_sanitized.sh gpu      GPU box: additionally a UBSan-only build (ASan cannot live beside the HIP runtime here) under
+#                                   the canary / malformed-weight-file / WAV-to-tokens / host-harness / decode-policy GPU tests
 # Exit status: pytest's.  A sanitizer report aborts the python process (halt_on_error), i.e. fails the run.
 set -e
 cd "$(dirname "$0")/.."
@@ -21,6 +21,11 @@ export WM_FUZZ_EXAMPLES=${WM_FUZZ_EXAMPLES:-600}
 SKIP="not exports_only_the_public_header and not environment_variables"   # properties of the PRODUCT .so file itself
 LD_PRELOAD=$RT python -m pytest tests/test_fuzz_cpu.py tests/test_abi.py tests/test_detok_cpu.py tests/test_sharding_cpu.py -q -x -m "not gpu" -k "$SKIP"
 if [ "$1" = gpu ]; then
-  # (handle_abort: a stack for an abort() raised below us, e.g. by the HIP runtime)
-  ASAN_OPTIONS=$ASAN_OPTIONS:handle_abort=1 LD_PRELOAD=$RT python -m pytest tests/test_canary_gpu.py tests/test_frontend_gpu.py -q -x -m gpu
+  # GPU box: hipInit aborts under the AddressSanitizer runtime (shadow memory vs the HSA address-space reservation; no ASan
+  # build of ROCm in this image), so the GPU leg is UBSan (signed overflow, bad shifts, misaligned / null access, float ->
+  # int overflow, array bounds on every host-side size computation) + the guard-band canaries around every caller-owned buffer
+  python openai-whisper-coreml_amd/build.py --ubsan
+  export WM_LIB_PATH=$PWD/openai-whisper-coreml_amd/libwhisper_mi355x_ubsan.so WM_DBG_LIB_PATH=$PWD/openai-whisper-coreml_amd/libwhisper_mi355x_ubsan.so
+  python -m pytest tests/test_canary_gpu.py tests/test_frontend_gpu.py tests/test_fuzz_cpu.py tests/test_model_gpu.py -q -x -m "gpu or not gpu" \
+      -k "canar or malformed or guarded or generate_spectrogram or frontend or fuzz or wav or error_paths or harness or swift_surface or detect_language or timestamp or early_stop_equals or suppress"
 fi
