@@ -435,7 +435,9 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
     int pos = 0;
     unsigned mword0 = 0u, mword1 = 0u;
     GemvUnitOps<EPI, LN> ops;
-    const int RS = NU * 4 <= NW ? 4 : 1;        // waves per unit in the epilogue (workgroup-uniform)
+    // (a single sequence has one row to finish: four waves would only add their operand loads and LDS reads -- measured
+    // +2 % per position at tiny.en / base with one chunk)
+    const int RS = (NU * 4 <= NW && p.B > 1) ? 4 : 1;   // waves per unit in the epilogue (workgroup-uniform)
     const int ntask = NU * RS;
     const bool has_unit = wave < ntask;         // wave-uniform: this wave finishes (part of) a unit
     const int my_u = wave / RS;
@@ -478,7 +480,7 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
                                                                  __builtin_bit_cast(bf16x8, wf[t][u]), a4, 0, 0, 0);
                 acc[j][t] = a4;
             }
-        {   // (every wave's part goes through LDS: with the rows of a unit split over four waves nobody finishes alone)
+        if (PPW > 1 || NU > 1 || wave != 0 || RS == 4) {  // (wave 0 finishing its own part alone needs no copy of it)
 #pragma unroll
             for (int j = 0; j < NBLK; ++j)
 #pragma unroll
@@ -516,7 +518,7 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
             for (int w = 1; w < NP; ++w) s1 += rp[w * NU * 256];
             sum = f32x4{s1, s1, s1, s1};  // (the epilogue looks at component my_r0 only)
         } else {
-            sum = *(const f32x4 *)(red + ((0 * NU + u) * 64 + lane) * 4);
+            sum = (NU == 1 && PPW == 1) ? acc[0][0] : *(const f32x4 *)(red + ((0 * NU + u) * 64 + lane) * 4);
             for (int w = 1; w < NP; ++w) sum += *(const f32x4 *)(red + ((w * NU + u) * 64 + lane) * 4);
         }
         gemv_unit_epilogue<EPI, LN>(p, ops, sum, st, tile, b0, lane, pos, mword0, mword1, my_r0, my_r1);
@@ -705,6 +707,25 @@ __global__ __launch_bounds__(LB) void dec_rows_attn_kernel(
     // nothing of the block can be consumed before all of it was requested (round 5: a re-ordered argument list was enough
     // for the compiler to issue 6 of the 8 loads, start on the scores, and issue the last two afterwards -- 13.7 -> 16.5 us
     // at 8 sequences: the stream is bound by bytes in flight per CU)
+    // The STREAMING shape (NS = 8, block by block: the kernel that carries the roofline) issues the 2 U loads of a block as
+    // inline asm, in program order -- K0 V0 K1 V1 ... -- and waits for them with COUNTED waits inside process_block.
+    // (Loads complete in order, so a count written for these 2 U requests only gets stricter if a load or store of the
+    // compiler's own is in flight beside them; the loaded registers are touched by nothing but the waiting asm before it.)
+    auto stream_block = [&](const bf16_t *kb, const bf16_t *vb, int r0, int clamp, u32x4 (&kv)[U], u32x4 (&vv)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int i = r0 + u * (NS * 8) + stream * 8 + rg;
+            i = i < clamp ? i : clamp;  // clamped: unconditional loads
+            const bf16_t *pk = kb + (long)i * 64, *pv = vb + (long)i * 64;
+            if (NT) {
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(kv[u]) : "v"(pk) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(vv[u]) : "v"(pv) : "memory");
+            } else {
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(kv[u]) : "v"(pk) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vv[u]) : "v"(pv) : "memory");
+            }
+        }
+    };
     auto block_fence = [](u32x4 (&kv)[U], u32x4 (&vv)[U]) {
         static_assert(U == 4, "block_fence is written for 4 loads per block");
         asm volatile("" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]));
@@ -753,12 +774,23 @@ __global__ __launch_bounds__(LB) void dec_rows_attn_kernel(
         float m_run = -1e30f, l_run = 0.f;
         float oa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         // one block of U x 8 rows of this stream: scores, block maximum, rescale, accumulate -- the stream's arithmetic
-        auto process_block = [&](int r0, const u32x4 (&kv)[U], const u32x4 (&vv)[U]) {
+        // counted: the block was requested by stream_block (inline-asm loads, K and V of row group u are requests 2u and
+        // 2u + 1 of 2 U); the counted wait in front of row group u's score carries the PREVIOUS score through the same asm, so
+        // that score u - 1 is computed before the wave waits for row group u -- scores under the tail of the loads, the
+        // schedule the round-4 build had from the compiler (67.7 us at 56 sequences; a wait for all eight: 69.3)
+        auto process_block = [&](int r0, u32x4 (&kv)[U], u32x4 (&vv)[U], bool counted) {
             float sc[U];
             float mb = -1e30f;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = r0 + u * (NS * 8) + stream * 8 + rg;
+                if (counted) {
+                    static_assert(U == 4, "the counted waits are written for 4 row groups per block");
+                    if (u == 0) asm volatile("s_waitcnt vmcnt(7)" : "+v"(kv[0])::"memory");
+                    if (u == 1) asm volatile("s_waitcnt vmcnt(5)" : "+v"(kv[1]), "+v"(mb)::"memory");
+                    if (u == 2) asm volatile("s_waitcnt vmcnt(3)" : "+v"(kv[2]), "+v"(mb)::"memory");
+                    if (u == 3) asm volatile("s_waitcnt vmcnt(1)" : "+v"(kv[3]), "+v"(mb)::"memory");
+                }
                 float a = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -771,6 +803,7 @@ __global__ __launch_bounds__(LB) void dec_rows_attn_kernel(
                 sc[u] = i < n_keys ? a : -1e30f;
                 mb = fmaxf(mb, sc[u]);
             }
+            if (counted) asm volatile("s_waitcnt vmcnt(0)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(mb)::"memory");
             mb = fmaxf(mb, __shfl_xor(mb, 8));
             mb = fmaxf(mb, __shfl_xor(mb, 16));
             mb = fmaxf(mb, __shfl_xor(mb, 32));
@@ -800,17 +833,22 @@ __global__ __launch_bounds__(LB) void dec_rows_attn_kernel(
             // was requested above (48 x 16 B per lane); the same block arithmetic in the same order: same bits.
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk)
-                if (blk * (NS * 8 * U) < n_keys) process_block(blk * (NS * 8 * U), kall[blk], vall[blk]);  // workgroup-uniform
+                if (blk * (NS * 8 * U) < n_keys) process_block(blk * (NS * 8 * U), kall[blk], vall[blk], false);  // workgroup-uniform
         } else {
             if (SPEC) {
                 block_fence(kall[0], vall[0]);
-                process_block(0, kall[0], vall[0]);
+                process_block(0, kall[0], vall[0], false);
             }
             for (int r0 = SPEC ? NS * 8 * U : 0; r0 < n_keys; r0 += NS * 8 * U) {  // workgroup-uniform trip count
                 u32x4 kv[U], vv[U];
-                load_block(kb, vb, r0, n_keys - 1, kv, vv);
-                block_fence(kv, vv);
-                process_block(r0, kv, vv);
+                if (SPEC) {
+                    load_block(kb, vb, r0, n_keys - 1, kv, vv);
+                    block_fence(kv, vv);
+                    process_block(r0, kv, vv, false);
+                } else {
+                    stream_block(kb, vb, r0, n_keys - 1, kv, vv);
+                    process_block(r0, kv, vv, true);
+                }
             }
         }
 #pragma unroll
