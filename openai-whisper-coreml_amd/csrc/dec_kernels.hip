@@ -85,6 +85,7 @@ struct DecGemvDev {
     const char *pf_ptr;    // next GEMV's weights: extra workgroups pull them into this XCD's L2
     long pf_tile_bytes;    // bytes of one 16-row weight tile of that matrix
     int pf_tiles;
+    int pf_head_major;     // warm-up placement for a consumer that runs head h on XCD h % 8 (dec_xattn_fq_kernel)
     int bgroups;           // workgroups per tile group along the batch: group g takes batch rows [g, g + 1) * NBLK * 16
 };
 
@@ -367,7 +368,13 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
     const int tg = G == 1 ? wg : (q / G) * 8 + (wg & 7);
     const int grp = G == 1 ? 0 : q % G;
     if (wg >= p.n_tg_pad * G || tg >= p.n_tg) {  // workgroup-uniform: warm-up workgroups and padding
-        const int t = wg - p.n_tg_pad * G;
+        int t = wg - p.n_tg_pad * G;
+        if (p.pf_head_major && t >= 0) {
+            // the next launch is the fused query + cross-attention kernel: head h's four tiles are consumed on XCD h % 8
+            // (dec_xattn_fq_kernel): warm-up workgroup 8 m + r (XCD r) pulls tile (m % 4) of head r + 8 (m / 4)
+            const int hh = (t & 7) + 8 * ((t >> 3) >> 2);
+            t = hh * 4 < p.pf_tiles ? hh * 4 + ((t >> 3) & 3) : -1;
+        }
         if (t >= 0 && t < p.pf_tiles) l2_warm_tile(p.pf_ptr, p.pf_tile_bytes, t, NW * 64);
         return;
     }
@@ -648,8 +655,8 @@ struct AttnCold {
     const char *pf_ptr;
     long pf_tile_bytes;
 };
-template <int NS, int U, bool NT, bool DEEP = false, int LB = (DEEP ? 256 : NS * 64)>
-__global__ __launch_bounds__(LB) void dec_rows_attn_kernel(
+template <int NS, int U, bool NT, bool DEEP = false>
+__global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_rows_attn_kernel(
     const float *__restrict__ q, const bf16_t *__restrict__ kc, const bf16_t *__restrict__ vc,
     const int *__restrict__ pos_ptr, const int *__restrict__ live_rows /* [WM_DEC_MAXB] rows | [1] count, or null */,
     unsigned packA /* H | nsplit << 8 | flat_wpw << 16 */, unsigned packB /* T_stride | n_keys_const << 16 */,
@@ -884,6 +891,371 @@ __global__ __launch_bounds__(LB) void dec_rows_attn_kernel(
         if (tid < 64)  // head outputs feed the out-projection GEMV: stored in its fragment-tiled A-operand order
             cold.att[wm_tiled_offset((size_t)b, (size_t)(h * 64 + tid), (size_t)d)] = f2bf(attn_merge<NS>(wm_, wl_, &wo_[0][0], 64, tid));
     }
+}
+
+// The CROSS-attention family (NS = 8: streaming shape, flat deal, deep flat deal) keeps the round-4 body verbatim: its
+// block loop is the kernel that carries the roofline (66.8 us for 430 MB at 56 sequences), and every restructuring of it
+// tried in round 5 -- peeled first block, fenced loads, asm-issued loads with counted waits -- left it 1-3 % slower
+// (68.0 - 68.8 us) although the loads were in flight earlier: the compiler's schedule of THIS source (packed FMAs across
+// row groups, 196 instructions per block) is the one measured.  Only the argument list is the new one (hot scalars first,
+// packed, preloaded); the key count of a cross-attention is an argument, so nothing here waits for the position.
+template <int NS, int U, bool NT, bool DEEP = false>
+__global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_xrows_attn_kernel(
+    const float *__restrict__ q, const bf16_t *__restrict__ kc, const bf16_t *__restrict__ vc,
+    const int *__restrict__ pos_ptr, const int *__restrict__ live_rows /* [WM_DEC_MAXB] rows | [1] count, or null */,
+    unsigned packA /* H | nsplit << 8 | flat_wpw << 16 */, unsigned packB /* T_stride | n_keys_const << 16 */,
+    unsigned packC /* n_bh | n_wg << 16 */, AttnCold cold) {
+    const int H = (int)(packA & 0xffu), nsplit = (int)((packA >> 8) & 0xffu), flat_wpw = (int)(packA >> 16);
+    const int T_stride = (int)(packB & 0xffffu), n_keys_const = (int)(packB >> 16);
+    int n_bh = (int)(packC & 0xffffu);
+    const int n_wg = (int)(packC >> 16);
+    const int d = H * 64;
+    const int *n_live_ptr = live_rows ? live_rows + WM_DEC_MAXB : nullptr;
+    bf16_t *att = cold.att;
+    float *part = cold.part;
+    const char *pf_ptr = cold.pf_ptr;
+    const long pf_tile_bytes = cold.pf_tile_bytes;
+    if ((int)blockIdx.x >= n_wg) {  // L2 warm-up workgroup for the next GEMV's weights
+        l2_warm_tile(pf_ptr, pf_tile_bytes, (int)blockIdx.x - n_wg, blockDim.x);
+        return;
+    }
+    // Early stop: sequences that have emitted <|endoftext|> (or used up their token budget) leave the decode group.
+    // The arg-max kernel keeps a COMPACT list of the live rows; the pairs walked here are (live row, head), dealt to the
+    // workgroups exactly like the full set, so the cache of a finished sequence is never read again and the remaining
+    // pairs stay balanced over the chip.  (null: every row is live -- the fixed-length benchmark decode.)
+    if (n_live_ptr) n_bh = *n_live_ptr * H;
+    __shared__ float wm_[NS], wl_[NS];
+    __shared__ float wo_[NS][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rg = lane >> 3, e8 = lane & 7;
+    const int n_keys = pos_ptr ? (*pos_ptr + 1) : n_keys_const;
+    const int last = n_keys - 1;
+    // FLAT launch (few pairs): the n_bh * NS (pair, stream) units are dealt to the waves of the grid one to one,
+    // flat_wpw waves per workgroup, so that every CU streams an equal share whatever the pair count (B = 8 x 20 heads:
+    // 1280 units = 256 workgroups of 5 waves); the waves of a workgroup are independent (partials to `part`, no barrier).
+    int stream = (int)blockIdx.y * (NS / nsplit) + wave;  // blockDim.x == (NS / nsplit) * 64
+    int bh0 = blockIdx.x, bh_step = n_wg;
+    if (flat_wpw > 0) {
+        const int unit = (int)blockIdx.x * flat_wpw + wave;
+        if (unit >= n_bh * NS) return;  // wave-uniform
+        bh0 = unit / NS;
+        stream = unit % NS;
+        bh_step = n_bh;  // one pair per wave
+    }
+    // n_wg <= n_bh workgroups (per split) walk the (sequence, head) pairs
+    for (int pi = bh0; pi < n_bh; pi += bh_step) {
+        if (flat_wpw == 0 && pi != (int)blockIdx.x) __syncthreads();  // the previous pair's merge has been read
+        const int h = pi % H;
+        const int b = live_rows ? live_rows[pi / H] : pi / H;
+        const int bh = b * H + h;
+        const bf16_t *kb = kc + (long)bh * T_stride * 64 + e8 * 8;
+        const bf16_t *vb = vc + (long)bh * T_stride * 64 + e8 * 8;
+        float qe[8];
+        {
+            const float *qp = q + (long)b * d + h * 64 + e8 * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qe[i] = qp[i] * 0.125f;  // hd^-0.5 (== hd^-0.25 on q and on k)
+        }
+        float m_run = -1e30f, l_run = 0.f;
+        float oa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto load_block = [&](int r0, u32x4 (&kv)[U], u32x4 (&vv)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int i = r0 + u * (NS * 8) + stream * 8 + rg;
+                i = i < n_keys ? i : last;  // clamped: unconditional loads
+                if (NT) {
+                    kv[u] = __builtin_nontemporal_load((const u32x4 *)(kb + (long)i * 64));
+                    vv[u] = __builtin_nontemporal_load((const u32x4 *)(vb + (long)i * 64));
+                } else {
+                    kv[u] = *(const u32x4 *)(kb + (long)i * 64);
+                    vv[u] = *(const u32x4 *)(vb + (long)i * 64);
+                }
+            }
+        };
+        // one block of U x 8 rows of this stream: scores, block maximum, rescale, accumulate -- the stream's arithmetic
+        auto process_block = [&](int r0, const u32x4 (&kv)[U], const u32x4 (&vv)[U]) {
+            float sc[U];
+            float mb = -1e30f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = r0 + u * (NS * 8) + stream * 8 + rg;
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a = __fmaf_rn(qe[2 * j], __uint_as_float(kv[u][j] << 16), a);
+                    a = __fmaf_rn(qe[2 * j + 1], __uint_as_float(kv[u][j] & 0xffff0000u), a);
+                }
+                a += __shfl_xor(a, 1);
+                a += __shfl_xor(a, 2);
+                a += __shfl_xor(a, 4);
+                sc[u] = i < n_keys ? a : -1e30f;
+                mb = fmaxf(mb, sc[u]);
+            }
+            mb = fmaxf(mb, __shfl_xor(mb, 8));
+            mb = fmaxf(mb, __shfl_xor(mb, 16));
+            mb = fmaxf(mb, __shfl_xor(mb, 32));
+            const float m_new = fmaxf(m_run, mb);
+            const float resc = __expf(m_run - m_new);  // 0 on the first block (m_run = -1e30), 1 when the max is unchanged
+            l_run *= resc;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) oa[j] *= resc;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float pv = sc[u] > -1e29f ? __expf(sc[u] - m_new) : 0.f;
+                l_run += pv;  // the 8 lanes of a row hold the same pv: only the row groups are summed below
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    oa[2 * j] = __fmaf_rn(pv, __uint_as_float(vv[u][j] << 16), oa[2 * j]);
+                    oa[2 * j + 1] = __fmaf_rn(pv, __uint_as_float(vv[u][j] & 0xffff0000u), oa[2 * j + 1]);
+                }
+            }
+            m_run = m_new;
+        };
+        if (DEEP) {
+            // LATENCY shape (a handful of pairs: tiny.en single chunk = 48 waves on the whole chip): a stream's rows are
+            // <= 6 blocks, and walking them one dependent memory round trip at a time was 9.2 us for 2.3 MB.  Request
+            // EVERY block first (48 x 16 B per lane), then run the same block arithmetic in the same order: same bits.
+            constexpr int NB = ATT_MAXK / (NS * 8 * U);
+            u32x4 kall[NB][U], vall[NB][U];
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) load_block(blk * (NS * 8 * U), kall[blk], vall[blk]);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+                if (blk * (NS * 8 * U) < n_keys) process_block(blk * (NS * 8 * U), kall[blk], vall[blk]);  // workgroup-uniform
+        } else {
+            for (int r0 = 0; r0 < n_keys; r0 += NS * 8 * U) {  // workgroup-uniform trip count
+                u32x4 kv[U], vv[U];
+                load_block(r0, kv, vv);
+                process_block(r0, kv, vv);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            oa[i] += __shfl_xor(oa[i], 8);
+            oa[i] += __shfl_xor(oa[i], 16);
+            oa[i] += __shfl_xor(oa[i], 32);
+        }
+        l_run += __shfl_xor(l_run, 8);
+        l_run += __shfl_xor(l_run, 16);
+        l_run += __shfl_xor(l_run, 32);
+        if (nsplit > 1) {  // workgroup-uniform: the stream partials go to HBM, dec_attn_combine_kernel merges them
+            if (rg == 0) {
+                float *po = part + ((long)bh * NS + stream) * 66;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) po[2 + e8 * 8 + i] = oa[i];
+                if (e8 == 0) {
+                    po[0] = m_run;
+                    po[1] = l_run;
+                }
+            }
+            continue;
+        }
+        if (rg == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wo_[wave][e8 * 8 + i] = oa[i];
+            if (e8 == 0) {
+                wm_[wave] = m_run;
+                wl_[wave] = l_run;
+            }
+        }
+        __syncthreads();
+        if (tid < 64)  // head outputs feed the out-projection GEMV: stored in its fragment-tiled A-operand order
+            att[wm_tiled_offset((size_t)b, (size_t)(h * 64 + tid), (size_t)d)] = f2bf(attn_merge<NS>(wm_, wl_, &wo_[0][0], 64, tid));
+    }
+}
+
+
+// ------------------------------------------------------------------ fused query projection + cross-attention
+// LATENCY shape of a decoder layer's cross-attention (round 5): 96 .. 256 (sequence, head) pairs -- a batch of 5 .. 12 at 20
+// heads -- and nothing else decoding on the device.  There the cross_attn_ln + query GEMV is a 3.6 us launch that does
+// 0.8 us of streaming, and its only consumer is the attention kernel behind it.  This kernel is both: the workgroup of
+// pair (b, h) first forms ITS OWN 64 query values -- the four 16-row weight tiles of head h, multiplied with the block of
+// 16 residual rows that holds b, K split over the waves exactly as dec_gemv_kernel splits it, partials summed through LDS
+// in part order, LayerNorm fold applied by the very functions the GEMV uses (gemv_unit_load / gemv_unit_stats): the 64
+// values are bit for bit what the GEMV would have left in HBM -- while the first block of its K/V rows is already on its
+// way, then walks its six blocks like the streaming kernel (stream_block / process_block arithmetic, same order: same
+// bits).  One launch and one kernel boundary less per layer.  Workgroup -> pair: all workgroups of head h sit on XCD
+// h % 8 (workgroup id % 8, observed placement), so a head's 164 KB weight slice crosses the fabric once and is an L2 hit
+// for the other sequences; the L2 warm-up workgroups of the previous launch place the tiles the same way (pf_head_major).
+struct FqCold {
+    const float *c1, *c2, *stats_in, *mean_in;
+    float *mean_out;
+    bf16_t *att;
+    long stats_stride;
+    int K, N;
+    const char *pf_ptr;    // L2 warm-up of the NEXT launch's weights by extra workgroups (as in dec_rows_attn_kernel)
+    long pf_tile_bytes;
+    int n_wg;              // compute workgroups; ids beyond are warm-up workgroups
+};
+template <int SPW, bool NT>
+__global__ __launch_bounds__(512) void dec_xattn_fq_kernel(const bf16_t *__restrict__ Wq, const bf16_t *__restrict__ xb,
+                                                           const bf16_t *__restrict__ kc, const bf16_t *__restrict__ vc,
+                                                           const int *__restrict__ live_rows, unsigned packA /* H | B << 8 */,
+                                                           unsigned packB /* T_stride | n_keys << 16 */, int K, FqCold cold) {
+    constexpr int NS = 8, U = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = (int)(packA & 0xffu), B = (int)(packA >> 8);
+    const int T_stride = (int)(packB & 0xffffu), n_keys = (int)(packB >> 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rg = lane >> 3, e8 = lane & 7;
+    // workgroup -> (head, sequence): residue r = id % 8 is the XCD; the heads r, r + 8, r + 16 live there
+    if ((int)blockIdx.x >= cold.n_wg) {  // L2 warm-up workgroup for the next GEMV's weights
+        l2_warm_tile(cold.pf_ptr, cold.pf_tile_bytes, (int)blockIdx.x - cold.n_wg, 512);
+        return;
+    }
+    const int r8 = (int)blockIdx.x & 7, kk = (int)blockIdx.x >> 3;
+    const int h = r8 + 8 * (kk / B), bi = kk % B;
+    if (h >= H) return;  // workgroup-uniform
+    int n_live = B;
+    if (live_rows) n_live = live_rows[WM_DEC_MAXB];
+    int b = bi;
+    if (live_rows) b = live_rows[bi];  // (bi < B: a possibly stale, valid row id; discarded below when bi >= n_live)
+    const int NP = (K >> 5) / SPW;     // K parts == waves that multiply (<= 8)
+    const int blk = b >> 4, bl = b & 15;
+    float *red = (float *)smem;                    // [NP][4 tiles][64][4]
+    float *stbase = red + NP * 4 * 256;            // [4][32] statistics slots, one per tile wave
+    float *q_lds = stbase + 4 * 32;                // [64]
+    // ---- every load in flight: the head's weight tiles and the residual block (waves < NP) ...
+    u32x4 wf[4][SPW], af[SPW];
+    if (wave < NP) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16_t *wp = Wq + (((long)(h * 4 + t) * (K >> 5) + (long)wave * SPW) * 64 + lane) * 8;
+#pragma unroll
+            for (int u = 0; u < SPW; ++u) wf[t][u] = *(const u32x4 *)(wp + u * 512);
+        }
+        const bf16_t *ap = xb + (((long)blk * (K >> 5) + (long)wave * SPW) * 64 + lane) * 8;
+#pragma unroll
+        for (int u = 0; u < SPW; ++u) af[u] = *(const u32x4 *)(ap + u * 512);
+    }
+    // ... the LayerNorm operands of the tile this wave will finish (waves 0 .. 3: tile h * 4 + wave) ...
+    DecGemvDev p = {};
+    p.B = B; p.N = cold.N; p.K = K; p.c1 = cold.c1; p.c2 = cold.c2; p.stats_in = cold.stats_in;
+    p.stats_stride = cold.stats_stride; p.mean_in = cold.mean_in; p.mean_out = cold.mean_out;
+    p.out_f32 = nullptr; p.ts.rng = nullptr;
+    GemvUnitOps<DE_Q, true> ops;
+    const int my_tile = h * 4 + (wave & 3);
+    if (wave < 4) gemv_unit_load<DE_Q, true>(p, ops, my_tile, blk * 16, lane, 0, 4, true);
+    // ... and the first block of this stream's K/V rows (stream = wave)
+    const int stream = wave;
+    const int bh = b * H + h;
+    const bf16_t *kb = kc + (long)bh * T_stride * 64 + e8 * 8;
+    const bf16_t *vb = vc + (long)bh * T_stride * 64 + e8 * 8;
+    auto load_block = [&](int r0, u32x4 (&kv)[U], u32x4 (&vv)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int i = r0 + u * (NS * 8) + stream * 8 + rg;
+            i = i < n_keys - 1 ? i : n_keys - 1;  // clamped: unconditional loads
+            if (NT) {
+                kv[u] = __builtin_nontemporal_load((const u32x4 *)(kb + (long)i * 64));
+                vv[u] = __builtin_nontemporal_load((const u32x4 *)(vb + (long)i * 64));
+            } else {
+                kv[u] = *(const u32x4 *)(kb + (long)i * 64);
+                vv[u] = *(const u32x4 *)(vb + (long)i * 64);
+            }
+        }
+    };
+    u32x4 kv0[U], vv0[U];
+    load_block(0, kv0, vv0);
+    if (bi >= n_live) return;  // (workgroup-uniform) the speculative pair is not live
+    // ---- the query: products of this wave's K part, split-K sum through LDS in part order, LayerNorm fold
+    if (wave < NP) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < SPW; ++u)
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[u]), __builtin_bit_cast(bf16x8, wf[t][u]), a4, 0, 0, 0);
+            *(f32x4 *)(red + ((wave * 4 + t) * 64 + lane) * 4) = a4;
+        }
+    }
+    if (wave < 4) gemv_unit_stats<DE_Q, true>(p, ops, stbase + wave * 32, lane, my_tile, blk * 16);
+    __syncthreads();
+    if (wave < 4) {
+        f32x4 sum = *(const f32x4 *)(red + ((0 * 4 + wave) * 64 + lane) * 4);
+        for (int w = 1; w < NP; ++w) sum += *(const f32x4 *)(red + ((w * 4 + wave) * 64 + lane) * 4);
+        const float2 ms = *(const float2 *)(stbase + wave * 32 + bl * 2);
+        const int kq = lane >> 4, nrow = lane & 15;
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (kq * 4 + r == bl) v = __fmaf_rn(ms.x, sum[r], __fmaf_rn(ms.y, ops.c1v, ops.c2v));  // == gemv_unit_epilogue (LN)
+        if (kq == (bl >> 2)) q_lds[wave * 16 + nrow] = v;
+    }
+    __syncthreads();
+    float qe[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qe[i] = q_lds[e8 * 8 + i] * 0.125f;  // hd^-0.5 (== hd^-0.25 on q and on k)
+    // ---- the stream: the block arithmetic of dec_rows_attn_kernel, block by block
+    float m_run = -1e30f, l_run = 0.f;
+    float oa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto process_block = [&](int r0, const u32x4 (&kv)[U], const u32x4 (&vv)[U]) {
+        float sc[U];
+        float mb = -1e30f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = r0 + u * (NS * 8) + stream * 8 + rg;
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a = __fmaf_rn(qe[2 * j], __uint_as_float(kv[u][j] << 16), a);
+                a = __fmaf_rn(qe[2 * j + 1], __uint_as_float(kv[u][j] & 0xffff0000u), a);
+            }
+            a += __shfl_xor(a, 1);
+            a += __shfl_xor(a, 2);
+            a += __shfl_xor(a, 4);
+            sc[u] = i < n_keys ? a : -1e30f;
+            mb = fmaxf(mb, sc[u]);
+        }
+        mb = fmaxf(mb, __shfl_xor(mb, 8));
+        mb = fmaxf(mb, __shfl_xor(mb, 16));
+        mb = fmaxf(mb, __shfl_xor(mb, 32));
+        const float m_new = fmaxf(m_run, mb);
+        const float resc = __expf(m_run - m_new);
+        l_run *= resc;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oa[j] *= resc;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float pv = sc[u] > -1e29f ? __expf(sc[u] - m_new) : 0.f;
+            l_run += pv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                oa[2 * j] = __fmaf_rn(pv, __uint_as_float(vv[u][j] << 16), oa[2 * j]);
+                oa[2 * j + 1] = __fmaf_rn(pv, __uint_as_float(vv[u][j] & 0xffff0000u), oa[2 * j + 1]);
+            }
+        }
+        m_run = m_new;
+    };
+    process_block(0, kv0, vv0);
+    for (int r0 = NS * 8 * U; r0 < n_keys; r0 += NS * 8 * U) {  // workgroup-uniform trip count
+        u32x4 kv[U], vv[U];
+        load_block(r0, kv, vv);
+        asm volatile("" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]));
+        process_block(r0, kv, vv);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        oa[i] += __shfl_xor(oa[i], 8);
+        oa[i] += __shfl_xor(oa[i], 16);
+        oa[i] += __shfl_xor(oa[i], 32);
+    }
+    l_run += __shfl_xor(l_run, 8);
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+    float *wm_ = red, *wl_ = red + NS, *wo_ = red + 2 * NS;  // (the split-K partials are dead: both barriers passed)
+    __syncthreads();
+    if (rg == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wo_[wave * 64 + e8 * 8 + i] = oa[i];
+        if (e8 == 0) {
+            wm_[wave] = m_run;
+            wl_[wave] = l_run;
+        }
+    }
+    __syncthreads();
+    if (tid < 64)
+        cold.att[wm_tiled_offset((size_t)b, (size_t)(h * 64 + tid), (size_t)(H * 64))] = f2bf(attn_merge<NS>(wm_, wl_, wo_, 64, tid));
 }
 
 // Merge the NS stream partials of every pair -> bf16 head outputs (same arithmetic as the in-kernel merge).
@@ -1325,7 +1697,9 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
         p.pf_ptr = (const char *)a.pf_ptr;
         p.pf_tile_bytes = 16L * a.pf_k * 2;
         p.pf_tiles = a.pf_rows / 16;
-        grid += p.pf_tiles;
+        p.pf_head_major = a.pf_head_major;
+        // head-major: 8 residues x 4 tiles x ceil(heads / 8) warm-up workgroups (some idle when heads % 8 != 0)
+        grid += a.pf_head_major ? 32 * ((p.pf_tiles / 4 + 7) / 8) : p.pf_tiles;
     }
     switch (a.epi * 2 + (ln ? 1 : 0)) {
         case DE_QKV * 2 + 1: {
@@ -1436,15 +1810,15 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
             const unsigned pC = (unsigned)(B * H) | ((unsigned)g << 16);
             WM_REQUIRE(g < 65536, WM_ERR_INVALID, "dec_attention: flat grid too large");
             if (g_wm_tuning.xattn_no_deep)
-                dec_rows_attn_kernel<8, 4, WM_XATTN_NT><<<g, wpw * 64, 0, ctx->stream>>>(
+                dec_xrows_attn_kernel<8, 4, WM_XATTN_NT><<<g, wpw * 64, 0, ctx->stream>>>(
                     q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
             // a cache of <= 3.2 MB per layer (tiny.en / base, single chunk) stays in the L2s from one position to the next
             // when it is read with cacheable loads: -1 .. -2 % per position there; +5 % at `small` (4.6 MB): the rule
             else if ((size_t)B * H * T_stride * 64 * 2 * 2 <= (size_t)3200 * 1024)
-                dec_rows_attn_kernel<8, 4, false, true><<<g, wpw * 64, 0, ctx->stream>>>(
+                dec_xrows_attn_kernel<8, 4, false, true><<<g, wpw * 64, 0, ctx->stream>>>(
                     q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
             else
-                dec_rows_attn_kernel<8, 4, WM_XATTN_NT, true><<<g, wpw * 64, 0, ctx->stream>>>(
+                dec_xrows_attn_kernel<8, 4, WM_XATTN_NT, true><<<g, wpw * 64, 0, ctx->stream>>>(
                     q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
         } else {
             dim3 grid(gx, nsplit);
@@ -1458,25 +1832,15 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
             const int lds_pad = g_wm_tuning.xattn_lds_pad;   // 84 KB
             static std::atomic<int> pad_set[64];  // per device (wm_multi: one process, every GPU of the node): the size allowed so far
             if (lds_pad > pad_set[ctx->device & 63].load(std::memory_order_acquire)) {
-                WM_HIP(hipFuncSetAttribute((const void *)dec_rows_attn_kernel<8, 4, WM_XATTN_NT>,
+                WM_HIP(hipFuncSetAttribute((const void *)dec_xrows_attn_kernel<8, 4, WM_XATTN_NT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_pad));
                 pad_set[ctx->device & 63].store(lds_pad, std::memory_order_release);
             }
             const AttnCold cold = {att, part, (const char *)pf_ptr, tile_bytes};
             const unsigned pA = (unsigned)H | ((unsigned)nsplit << 8), pB = (unsigned)T_stride | ((unsigned)n_keys << 16);
             const unsigned pC = (unsigned)(B * H) | ((unsigned)n_wg << 16);
-            // EXPERIMENT, off in the product (xattn_deep8_max_pairs = 0): fewer pairs than CUs (a batch of 5 .. 12 at 20
-            // heads) -- a workgroup owns ONE pair and its waves walk six blocks, one dependent memory round trip each, so
-            // every block of every stream requested up front (48 x 16 B per lane, 256 VGPRs) should have been the latency
-            // shape.  Measured: SLOWER -- 16.1 vs 13.8 us at 8 sequences, 1.764 vs 1.626 ms per position (large-v2), 0.212 vs
-            // 0.201 at tiny.en x 24: the stream is not short of bytes in flight; 8 waves x 48 requests per CU queue in front
-            // of the CU's own memory pipeline.  Same bits (the launch-shape tests run it through the debug knob).
-            if (nsplit == 1 && !short_lived && B * H <= g_wm_tuning.xattn_deep8_max_pairs && n_wg == B * H)
-                dec_rows_attn_kernel<8, 4, WM_XATTN_NT, true, 512><<<grid, 512, 0, ctx->stream>>>(
-                    q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
-            else
-                dec_rows_attn_kernel<8, 4, WM_XATTN_NT><<<grid, (8 / nsplit) * 64, (nsplit == 1 && !two_per_cu) ? lds_pad : 0, ctx->stream>>>(
-                    q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
+            dec_xrows_attn_kernel<8, 4, WM_XATTN_NT><<<grid, (8 / nsplit) * 64, (nsplit == 1 && !two_per_cu) ? lds_pad : 0, ctx->stream>>>(
+                q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
         }
         WM_HIP(hipGetLastError());
     }
@@ -1485,6 +1849,52 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
         dec_attn_combine_kernel<8><<<B * H, 64, 0, ctx->stream>>>(part, H, H * 64, att);
         WM_HIP(hipGetLastError());
     }
+    return WM_OK;
+}
+
+// Fused cross_attn_ln + query projection + cross-attention (dec_xattn_fq_kernel): the latency shape of 96 .. 256 pairs.
+// Returns WM_OK and *used = true when the shape was launched; *used = false: not applicable, the caller runs the two
+// separate launches (same results either way).
+bool wm_dec_xattn_fq_applies(int B, int H, int K, bool short_lived) {
+    if (!g_wm_tuning.xattn_fuse_q || short_lived) return false;
+    const int pairs = B * H;
+    if (pairs < g_wm_tuning.xattn_split_below || pairs > 256 || K != H * 64) return false;
+    int spw = 0;
+    const int nw = wm_dec_gemv_split(K, &spw);
+    return nw >= 1 && nw <= 8 && (spw == 2 || spw == 4 || spw == 5 || spw == 6);
+}
+
+int wm_dec_xattn_fq(wm_ctx *ctx, const DecGemvArgs &qa, const bf16_t *kc, const bf16_t *vc, int B, int H, int T_stride,
+                    int n_keys, bf16_t *att, const int *live_rows, const int *n_live, const bf16_t *pf_ptr, int pf_rows, int pf_k) {
+    WM_REQUIRE(qa.c1 && qa.stats_in && qa.N == qa.K && qa.K == H * 64, WM_ERR_INVALID, "xattn_fq: not a LayerNorm-folded d x d query projection");
+    WM_REQUIRE(H >= 1 && H <= 255 && B >= 1 && B <= WM_DEC_MAXB && T_stride <= ATT_MAXK && n_keys >= 1 && n_keys <= ATT_MAXK,
+               WM_ERR_INVALID, "xattn_fq: bad geometry");
+    WM_REQUIRE((!live_rows && !n_live) || n_live == live_rows + WM_DEC_MAXB, WM_ERR_INVALID, "xattn_fq: the live count must follow the live rows");
+    int spw = 0;
+    const int nw = wm_dec_gemv_split(qa.K, &spw);
+    WM_REQUIRE(nw >= 1 && nw <= 8, WM_ERR_INVALID, "xattn_fq: K split over more than 8 waves");
+    WmProfScope ps(&ctx->prof, "dec_attn_cross_fq", ctx->stream);
+    FqCold cold;
+    cold.c1 = qa.c1; cold.c2 = qa.c2; cold.stats_in = qa.stats_in; cold.mean_in = qa.mean_in; cold.mean_out = qa.mean_out;
+    cold.att = att; cold.stats_stride = 2L * qa.K; cold.K = qa.K; cold.N = qa.N;
+    const unsigned pA = (unsigned)H | ((unsigned)B << 8), pB = (unsigned)T_stride | ((unsigned)n_keys << 16);
+    int grid = 8 * ((H + 7) / 8) * B;
+    cold.n_wg = grid; cold.pf_ptr = nullptr; cold.pf_tile_bytes = 0;
+    if (pf_enabled(B) && pf_ptr && pf_rows >= 16) {
+        cold.pf_ptr = (const char *)pf_ptr;
+        cold.pf_tile_bytes = 16L * pf_k * 2;
+        grid += pf_rows / 16;
+    }
+    const size_t lds = ((size_t)nw * 1024 + 128 + 64) * sizeof(float);
+    hipStream_t s = ctx->stream;
+    switch (spw) {
+        case 2: dec_xattn_fq_kernel<2, WM_XATTN_NT><<<grid, 512, lds, s>>>(qa.W, qa.a, kc, vc, live_rows, pA, pB, qa.K, cold); break;
+        case 4: dec_xattn_fq_kernel<4, WM_XATTN_NT><<<grid, 512, lds, s>>>(qa.W, qa.a, kc, vc, live_rows, pA, pB, qa.K, cold); break;
+        case 5: dec_xattn_fq_kernel<5, WM_XATTN_NT><<<grid, 512, lds, s>>>(qa.W, qa.a, kc, vc, live_rows, pA, pB, qa.K, cold); break;
+        case 6: dec_xattn_fq_kernel<6, WM_XATTN_NT><<<grid, 512, lds, s>>>(qa.W, qa.a, kc, vc, live_rows, pA, pB, qa.K, cold); break;
+        default: wm_set_error("xattn_fq: unsupported k-steps per wave %d", spw); return WM_ERR_INVALID;
+    }
+    WM_HIP(hipGetLastError());
     return WM_OK;
 }
 

@@ -600,6 +600,9 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.a = m->datt; a.out_f32 = m->dx; a.out_bf16 = m->dxb; a.ldo = d; a.stats_out = m->dstats;
         a.mean_in = mean_buf(cur);
         a.pf_ptr = L.wxq_f; a.pf_rows = d; a.pf_k = d;
+        const bool xshort = m->xattn_shared && !g_wm_tuning.xattn_never_short;
+        const bool fuse_q = xns == 1 && wm_dec_xattn_fq_applies(B, H, d, xshort);
+        a.pf_head_major = fuse_q ? 1 : 0;
         WM_TRY(wm_dec_gemv(ctx, a));
         // 4. cross_attn_ln (folded) + query projection
         memset(&a, 0, sizeof(a));
@@ -607,10 +610,14 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.a = m->dxb; a.out_f32 = m->dq; a.ldo = d;
         a.stats_in = m->dstats;
         a.mean_in = mean_buf(cur); a.mean_out = mean_buf(cur ^ 1); cur ^= 1;
-        WM_TRY(wm_dec_gemv(ctx, a));
-        // 5. cross-attention over the 1500 cached encoder frames
-        WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, xns, m->dpart, m->datt, true, L.wxo, d, d, live, nlive,
-                                m->xattn_shared && !g_wm_tuning.xattn_never_short));
+        if (fuse_q) {
+            // 4 + 5 as ONE launch (the latency shape: every pair's workgroup forms its own query, dec_kernels.hip)
+            WM_TRY(wm_dec_xattn_fq(ctx, a, xk, xv, B, H, S, S, m->datt, live, nlive, L.wxo, d, d));
+        } else {
+            WM_TRY(wm_dec_gemv(ctx, a));
+            // 5. cross-attention over the 1500 cached encoder frames
+            WM_TRY(wm_dec_attention(ctx, m->dq, xk, xv, B, H, S, S, nullptr, xns, m->dpart, m->datt, true, L.wxo, d, d, live, nlive, xshort));
+        }
         // 6. out-projection + residual
         memset(&a, 0, sizeof(a));
         a.epi = DE_RESID; a.B = B; a.N = d; a.K = d; a.W = L.wxo; a.c2 = L.bxo;

@@ -307,8 +307,15 @@ struct DecGemvArgs {
     // optional L2 warm-up of the NEXT skinny GEMV's weights ([pf_rows][pf_k] bf16, WL_TILED)
     const bf16_t *pf_ptr;
     int pf_rows, pf_k;
+    int pf_head_major;     // the next launch is wm_dec_xattn_fq: place head h's tiles on XCD h % 8
 };
 int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a);
+// cross_attn_ln + query projection fused INTO the cross-attention launch (96 .. 256 pairs, alone on the device): qa = the
+// DE_Q LayerNorm-mode arguments the separate GEMV would get (out_f32 unused).  Same bits as the two launches.
+bool wm_dec_xattn_fq_applies(int B, int H, int K, bool short_lived);
+int wm_dec_xattn_fq(wm_ctx *ctx, const DecGemvArgs &qa, const bf16_t *kc, const bf16_t *vc, int B, int H, int T_stride,
+                    int n_keys, bf16_t *att, const int *live_rows, const int *n_live, const bf16_t *pf_ptr = nullptr,
+                    int pf_rows = 0, int pf_k = 0);
 // waves per workgroup and k-steps per wave the GEMV uses for a given K (a function of K only)
 int wm_dec_gemv_split(int K, int *spw);
 // W' = bf16(W g) (WL_TILED in, WL_TILED out), c1 = row sums of W', c2 = bias + W beta; rows N .. pad16(N) give zeros

@@ -173,8 +173,8 @@ struct WmTuning {
     int enc_attn_mfma_sum = 0;    // 1: encoder attention row sums by a ones-operand MFMA instead of f32 VALU adds
     int xattn_never_short = 0;    // 1: persistent cross-attention workgroups also when the chip is shared (rounds 2-3)
     int xattn_no_deep = 0;        // 1: the flat (few-pair) cross-attention walks its blocks one round trip at a time
-    int xattn_deep8_max_pairs = 0;    // EXPERIMENT (lost, profiles/r05_latency_probe.txt): 8-wave cross-attention with every block requested up front up to this many pairs
     int xattn_pair_wg_max_pairs = 0;  // EXPERIMENT (lost, same file): alone, 257 .. this many pairs: one cross-attention workgroup per pair, two per CU
+    int xattn_fuse_q = 1;         // 96 .. 256 pairs, alone: query projection fused into the cross-attention launch (0: two launches)
     int group_chunks = 0;         // preferred decode-group size of a wm_transcribe_greedy call (product rule: model_api.cpp)
 };
 extern WmTuning g_wm_tuning;   // api.cpp

@@ -1583,6 +1583,52 @@ def test_flat_cross_attention_launch_shapes_are_bitwise_equal(pkg):
     assert np.array_equal(solo[0], gen[1]) and len({r.tobytes() for r in gen}) == 3
 
 
+def test_fused_query_cross_attention_is_bitwise_equal_to_the_two_launches(pkg):
+    """Round 5: with 96 .. 256 (sequence, head) pairs and nothing else decoding on the device, cross_attn_ln + query projection
+    run INSIDE the cross-attention launch (dec_xattn_fq_kernel: every pair's workgroup forms its own 64 query values with the
+    GEMV's own K split, summation order and LayerNorm fold).  Same bits by construction -- checked here: large-v2 width (20
+    heads), 3 decoder layers, groups of 5 / 8 / 12 rows (100 / 160 / 240 pairs) with the fusion on (product) and off (debug
+    knob xattn_fuse_q = 0, a fresh context so that no captured graph is reused): teacher-forced logits and 40 greedy tokens
+    identical; with a stop token and per-row budgets (the fused kernel walks the live list) identical too; and a row decoded
+    in a group of 8 (fused) equals the same row alone (1 row: flat deal, separate GEMV)."""
+    import ctypes
+    dims = dict(pkg.binding.MODEL_DIMS["large-v2"], n_audio_layer=2, n_text_layer=3)
+    lib = pkg.binding.load_debug_library()
+    lib.wmdbg_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    pcm = np.stack([tone_chunk(i) if i % 2 else L.synth_chunk(500 + i) for i in range(12)])
+    prompt = [50258, 50259, 50359, 50363]
+    rng = np.random.default_rng(12)
+    tok = rng.integers(0, 51865, size=(12, 6)).astype(np.int32)
+    outs = []
+    try:
+        for fuse in (1, 0):
+            lib.wmdbg_set_tuning(b"reset", 0)
+            assert lib.wmdbg_set_tuning(b"xattn_fuse_q", fuse) == 0
+            ctx = pkg.binding.Context(dims, debug=True)
+            ctx.init_synthetic(41, matrix_gain=LIVELY_GAIN)
+            _perturb_ln_on_device(ctx, dims, seed=9)
+            ctx.finalize()
+            ctx.set_lanes(1)
+            xa = ctx.encode_mel(ctx.logmel(pcm, out_dtype=np.float32))
+            res = []
+            for n in (5, 8, 12):
+                res.append(ctx.decode_logits(tok[:n], xa[:n]))
+                res.append(ctx.transcribe_greedy(pcm[:n], prompt, 40)[0])
+            free = res[3]                                              # the 8-row greedy run
+            stop_tok = int(np.bincount(free[:, 5:].ravel()).argmax())      # a token that does occur: rows stop at different times
+            t_es, l_es = ctx.transcribe_greedy(pcm[:8], prompt, 40, eot=stop_tok, budgets=[40, 7, 40, 19, 3, 40, 40, 11])
+            res += [t_es, l_es, ctx.transcribe_greedy(pcm[2:3], prompt, 40)[0]]
+            outs.append(res)
+            ctx.close()
+    finally:
+        lib.wmdbg_set_tuning(b"reset", 0)
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    assert len({r.tobytes() for r in outs[0][3]}) >= 6
+    assert np.array_equal(outs[0][-1][0], outs[0][3][2])              # row 2 alone == row 2 in the fused group of 8
+    assert outs[0][-2].min() < 40                                     # the stop token / budgets did end rows early
+
+
 def test_cross_attention_persistent_and_short_lived_shapes_are_bitwise_equal_under_load(pkg):
     """which cross-attention launch shape a burst of positions gets (<= 256 persistent workgroups walking the
     pairs, or one short-lived workgroup per pair) is decided at run time from what else decodes on the device, so bit-level
