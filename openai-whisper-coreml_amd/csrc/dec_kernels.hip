@@ -370,10 +370,13 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
     if (wg >= p.n_tg_pad * G || tg >= p.n_tg) {  // workgroup-uniform: warm-up workgroups and padding
         int t = wg - p.n_tg_pad * G;
         if (p.pf_head_major && t >= 0) {
-            // the next launch is the fused query + cross-attention kernel: head h's four tiles are consumed on XCD h % 8
-            // (dec_xattn_fq_kernel): warm-up workgroup 8 m + r (XCD r) pulls tile (m % 4) of head r + 8 (m / 4)
-            const int hh = (t & 7) + 8 * ((t >> 3) >> 2);
-            t = hh * 4 < p.pf_tiles ? hh * 4 + ((t >> 3) & 3) : -1;
+            // the next launch is the fused query + cross-attention kernel (dec_xattn_fq_kernel): XCD x runs the pairs
+            // [x per, (x + 1) per) of the head-major pair list (per = pf_head_major), i.e. a few whole or half heads --
+            // warm-up workgroup 8 m + x (on XCD x) pulls tile m % 4 of the (m / 4)-th head that XCD x hosts
+            const int per = p.pf_head_major, x = t & 7, m = t >> 3;
+            const int hh = (x * per) / p.B + (m >> 2);
+            const int end = (x + 1) * per < (p.pf_tiles >> 2) * p.B ? (x + 1) * per : (p.pf_tiles >> 2) * p.B;
+            t = hh * p.B < end ? hh * 4 + (m & 3) : -1;
         }
         if (t >= 0 && t < p.pf_tiles) l2_warm_tile(p.pf_ptr, p.pf_tile_bytes, t, NW * 64);
         return;
@@ -445,9 +448,10 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
     // (a single sequence has one row to finish: four waves would only add their operand loads and LDS reads -- measured
     // +2 % per position at tiny.en / base with one chunk)
     const int RS = (NU * 4 <= NW && p.B > 1) ? 4 : 1;   // waves per unit in the epilogue (workgroup-uniform)
-    const int ntask = NU * RS;
+    const int rs_shift = RS == 4 ? 2 : 0;       // (shifts, not divisions by a run-time value: ~30 dependent instructions each)
+    const int ntask = NU << rs_shift;
     const bool has_unit = wave < ntask;         // wave-uniform: this wave finishes (part of) a unit
-    const int my_u = wave / RS;
+    const int my_u = wave >> rs_shift;
     const int my_r0 = RS == 4 ? (wave & 3) : 0, my_r1 = RS == 4 ? my_r0 + 1 : 4;
     const bool my_stats = my_r0 == 0;           // the wave that forms the unit's LayerNorm statistics
     int utile = tile0, ub0 = bb;
@@ -501,7 +505,7 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
     __syncthreads();
     // ---- 4. fused epilogues: task t = (unit, row share) on wave t % NW (the first task's operands are already here)
     for (int tk = wave; tk < ntask; tk += NW) {  // wave-uniform; RS == 4: at most one trip
-        const int u = tk / RS;
+        const int u = tk >> rs_shift;
         const int t = u % TN, j = u / TN;
         const int tile = tile0 + t, b0 = bb + j * 16;
         if (tile >= p.n_tiles || b0 >= p.B) continue;
@@ -1074,9 +1078,11 @@ __global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_xrows_attn_kernel(
 // in part order, LayerNorm fold applied by the very functions the GEMV uses (gemv_unit_load / gemv_unit_stats): the 64
 // values are bit for bit what the GEMV would have left in HBM -- while the first block of its K/V rows is already on its
 // way, then walks its six blocks like the streaming kernel (stream_block / process_block arithmetic, same order: same
-// bits).  One launch and one kernel boundary less per layer.  Workgroup -> pair: all workgroups of head h sit on XCD
-// h % 8 (workgroup id % 8, observed placement), so a head's 164 KB weight slice crosses the fabric once and is an L2 hit
-// for the other sequences; the L2 warm-up workgroups of the previous launch place the tiles the same way (pf_head_major).
+// bits).  One launch and one kernel boundary less per layer.  Workgroup -> pair: the head-major pair list is cut into 8
+// equal ranges, one per XCD (workgroup id % 8, observed placement), so every XCD streams the same number of caches and a
+// head's 164 KB weight slice crosses the fabric once or twice and is an L2 hit for the other sequences of the head; the
+// L2 warm-up workgroups of the previous launch place the tiles the same way (pf_head_major).  (A first version put head h
+// on XCD h % 8: 24 vs 16 workgroups per XCD at 20 heads x 8, and the stream ran at the pace of the fuller XCDs.)
 struct FqCold {
     const float *c1, *c2, *stats_in, *mean_in;
     float *mean_out;
@@ -1103,9 +1109,12 @@ __global__ __launch_bounds__(512) void dec_xattn_fq_kernel(const bf16_t *__restr
         l2_warm_tile(cold.pf_ptr, cold.pf_tile_bytes, (int)blockIdx.x - cold.n_wg, 512);
         return;
     }
-    const int r8 = (int)blockIdx.x & 7, kk = (int)blockIdx.x >> 3;
-    const int h = r8 + 8 * (kk / B), bi = kk % B;
-    if (h >= H) return;  // workgroup-uniform
+    // workgroup -> pair: the head-major pair list (h, b) is cut into 8 equal ranges, one per XCD (id % 8, observed
+    // placement): every XCD streams the same number of caches and hosts 2 - 4 heads' weight slices
+    const int per = (H * B + 7) >> 3;
+    const int pidx = ((int)blockIdx.x >> 3) + per * ((int)blockIdx.x & 7);
+    if (((int)blockIdx.x >> 3) >= per || pidx >= H * B) return;  // workgroup-uniform
+    const int h = pidx / B, bi = pidx % B;
     int n_live = B;
     if (live_rows) n_live = live_rows[WM_DEC_MAXB];
     int b = bi;
@@ -1697,9 +1706,9 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
         p.pf_ptr = (const char *)a.pf_ptr;
         p.pf_tile_bytes = 16L * a.pf_k * 2;
         p.pf_tiles = a.pf_rows / 16;
-        p.pf_head_major = a.pf_head_major;
-        // head-major: 8 residues x 4 tiles x ceil(heads / 8) warm-up workgroups (some idle when heads % 8 != 0)
-        grid += a.pf_head_major ? 32 * ((p.pf_tiles / 4 + 7) / 8) : p.pf_tiles;
+        p.pf_head_major = a.pf_head_major;   // = pairs per XCD of the fused consumer (0: plain placement, tile t on XCD t % 8)
+        // head-major: 8 XCDs x 4 tiles x the heads an XCD can host (a range of `per` pairs touches <= per / B + 2 heads)
+        grid += a.pf_head_major ? 32 * (a.pf_head_major / a.B + 2) : p.pf_tiles;
     }
     switch (a.epi * 2 + (ln ? 1 : 0)) {
         case DE_QKV * 2 + 1: {
@@ -1878,7 +1887,7 @@ int wm_dec_xattn_fq(wm_ctx *ctx, const DecGemvArgs &qa, const bf16_t *kc, const 
     cold.c1 = qa.c1; cold.c2 = qa.c2; cold.stats_in = qa.stats_in; cold.mean_in = qa.mean_in; cold.mean_out = qa.mean_out;
     cold.att = att; cold.stats_stride = 2L * qa.K; cold.K = qa.K; cold.N = qa.N;
     const unsigned pA = (unsigned)H | ((unsigned)B << 8), pB = (unsigned)T_stride | ((unsigned)n_keys << 16);
-    int grid = 8 * ((H + 7) / 8) * B;
+    int grid = 8 * ((H * B + 7) / 8);
     cold.n_wg = grid; cold.pf_ptr = nullptr; cold.pf_tile_bytes = 0;
     if (pf_enabled(B) && pf_ptr && pf_rows >= 16) {
         cold.pf_ptr = (const char *)pf_ptr;

@@ -602,7 +602,7 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.pf_ptr = L.wxq_f; a.pf_rows = d; a.pf_k = d;
         const bool xshort = m->xattn_shared && !g_wm_tuning.xattn_never_short;
         const bool fuse_q = xns == 1 && wm_dec_xattn_fq_applies(B, H, d, xshort);
-        a.pf_head_major = fuse_q ? 1 : 0;
+        a.pf_head_major = fuse_q ? (H * B + 7) / 8 : 0;   // pairs per XCD of the fused consumer
         WM_TRY(wm_dec_gemv(ctx, a));
         // 4. cross_attn_ln (folded) + query projection
         memset(&a, 0, sizeof(a));

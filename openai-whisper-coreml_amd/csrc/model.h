@@ -307,7 +307,7 @@ struct DecGemvArgs {
     // optional L2 warm-up of the NEXT skinny GEMV's weights ([pf_rows][pf_k] bf16, WL_TILED)
     const bf16_t *pf_ptr;
     int pf_rows, pf_k;
-    int pf_head_major;     // the next launch is wm_dec_xattn_fq: place head h's tiles on XCD h % 8
+    int pf_head_major;     // the next launch is wm_dec_xattn_fq: (pairs per XCD) place every head's tiles on the XCD(s) that run it
 };
 int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a);
 // cross_attn_ln + query projection fused INTO the cross-attention launch (96 .. 256 pairs, alone on the device): qa = the
