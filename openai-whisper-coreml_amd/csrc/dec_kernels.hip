@@ -347,7 +347,7 @@ __device__ __forceinline__ void gemv_unit_epilogue(const DecGemvDev &p, const Ge
 // before the first instruction (a by-value struct is never preloaded).  The cold fields stay in the struct; they are
 // requested in one burst right after the weight / activation loads (GEMV_PIN below).
 #define GEMV_PIN(x) asm volatile("" ::"s"(x))
-template <int SPW, int TN, int NBLK, int EPI, bool LN, int PPW = 1>
+template <int SPW, int TN, int NBLK, int EPI, bool LN, int PPW = 1, int RSP = 1>
 __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512 : 1024) void dec_gemv_kernel(
     const bf16_t *__restrict__ hotW, const bf16_t *__restrict__ hotA, const int *__restrict__ hot_pos_ptr,
     const float *__restrict__ hot_c2, int hotK, int hot_n_tiles, int hotB, int hot_bgroups, int hot_n_tg, int hot_n_tg_pad,
@@ -436,19 +436,20 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
         GEMV_PIN(p.mask_first_pos); GEMV_PIN(p.ts.rng); GEMV_PIN(p.ts.key_ts); GEMV_PIN(p.ts.lse); GEMV_PIN(p.ts.ts_begin);
     }
     // ... and the epilogue operands of the (tile, block) unit this wave will finish: unit u = j * TN + t -> wave u % NW
-    // ROW SPLIT (round 5).  The epilogue of a (tile, block) unit used to be ONE wave's work while the workgroup's other
-    // waves had already finished: ~200 dependent instructions (shuffles for the statistics / arg-max keys, erf, scattered
-    // stores) at one wave's issue rate -- the out-projection (residual epilogue) took 0.9 us longer than the query
-    // projection on the same matrix.  When the workgroup has at least four waves per unit, a unit's four accumulator
-    // rows per lane (batch rows kq * 4 + r) are finished by FOUR waves, one r each: wave 4 u + r takes row r of unit u.
-    // Same instructions per element, same order of the split-K sum: same bits.
+    // ROW SPLIT (round 5, template RSP = 4).  The epilogue of a (tile, block) unit used to be ONE wave's work while the
+    // workgroup's other waves had already finished: ~200 dependent instructions (shuffles for the statistics, scattered
+    // bf16 / f32 stores) at one wave's issue rate -- the out-projection (residual epilogue) took 0.9 us longer than the
+    // query projection on the same matrix.  In the RESIDUAL kernels, when the workgroup has at least four waves per unit
+    // and more than one sequence, a unit's four accumulator rows per lane (batch rows kq * 4 + r) are finished by FOUR
+    // waves, one r each: wave 4 u + r takes row r of unit u.  Same instructions per element, same order of the split-K sum:
+    // same bits.  (A compile-time choice per launch: as a run-time switch in every kernel it cost the LayerNorm GEMVs,
+    // whose epilogue is a single fma per row, 0.3 us each -- profiles/r05_latency_probe.txt.)
     int pos = 0;
     unsigned mword0 = 0u, mword1 = 0u;
     GemvUnitOps<EPI, LN> ops;
-    // (a single sequence has one row to finish: four waves would only add their operand loads and LDS reads -- measured
-    // +2 % per position at tiny.en / base with one chunk)
-    const int RS = (NU * 4 <= NW && p.B > 1) ? 4 : 1;   // waves per unit in the epilogue (workgroup-uniform)
-    const int rs_shift = RS == 4 ? 2 : 0;       // (shifts, not divisions by a run-time value: ~30 dependent instructions each)
+    constexpr int RS = RSP;                     // waves per unit in the epilogue
+    static_assert(RSP == 1 || RSP == 4, "row split: 1 or 4 waves per unit");
+    constexpr int rs_shift = RS == 4 ? 2 : 0;
     const int ntask = NU << rs_shift;
     const bool has_unit = wave < ntask;         // wave-uniform: this wave finishes (part of) a unit
     const int my_u = wave >> rs_shift;
@@ -1570,7 +1571,21 @@ int launch_gemv_shape(wm_ctx *ctx, const DecGemvDev &p, int tn, int nblk, int nw
         if (!TWO || tn != 1 || nblk != 1 || nw % 2) { wm_set_error("dec_gemv: no two-part kernel for this shape"); return WM_ERR_INVALID; }
         const int w2 = nw / 2;
         const size_t lds2 = (size_t)nw * 1024 + (size_t)w2 * 32 * 4;
-        dec_gemv_kernel<TWO ? SPW : 6, 1, 1, TWO ? EPI : DE_RESID, TWO ? LN : false, 2><<<grid, w2 * 64, lds2, s>>>(GEMV_ARGS(p));
+        // (row split, see the kernel: four waves per unit finish the residual epilogue; w2 >= 4 and more than one sequence)
+        if (w2 >= 4 && p.B > 1)
+            dec_gemv_kernel<TWO ? SPW : 6, 1, 1, TWO ? EPI : DE_RESID, TWO ? LN : false, 2, 4><<<grid, w2 * 64, lds2, s>>>(GEMV_ARGS(p));
+        else
+            dec_gemv_kernel<TWO ? SPW : 6, 1, 1, TWO ? EPI : DE_RESID, TWO ? LN : false, 2><<<grid, w2 * 64, lds2, s>>>(GEMV_ARGS(p));
+        WM_HIP(hipGetLastError());
+        return WM_OK;
+    }
+    constexpr bool RESID = !LN && EPI == DE_RESID;
+    const bool split = RESID && p.B > 1 && tn == 1 && nblk * 4 <= nw;   // four waves per (tile, block) unit
+    if (split && RESID) {
+        const size_t ldsr = (size_t)nw * nblk * 1024 + (size_t)nw * 32 * 4;
+        if (nblk == 1) dec_gemv_kernel<SPW, 1, 1, RESID ? EPI : DE_RESID, RESID ? LN : false, 1, 4><<<grid, nw * 64, ldsr, s>>>(GEMV_ARGS(p));
+        else if (nblk == 2 && SPW <= 8) dec_gemv_kernel<SPW <= 8 ? SPW : 2, 1, 2, RESID ? EPI : DE_RESID, RESID ? LN : false, 1, 4><<<grid, nw * 64, ldsr, s>>>(GEMV_ARGS(p));
+        else { wm_set_error("dec_gemv: unsupported row-split shape (nblk %d, spw %d)", nblk, SPW); return WM_ERR_INVALID; }
         WM_HIP(hipGetLastError());
         return WM_OK;
     }

@@ -4,8 +4,8 @@ Round 5 found that the round-4 kernel walked FOUR dependent scalar (kernarg) rou
 issued, and then -- twice in one afternoon -- that an innocent-looking edit (one cold struct field read in front of the
 loads) puts such a trip back without any test noticing: the results are identical, only every one of the ~190 GEMV
 launches of a decoder position is 0.3 us slower.  This test pins the property in the machine code: in every
-dec_gemv_kernel instantiation, the straight-line code that issues the first weight loads contains no scalar load and no
-scalar-memory wait (the leading arguments arrive preloaded in SGPRs; csrc/dec_kernels.hip "KERNEL ARGUMENTS").
+dec_gemv_kernel instantiation, the straight-line code that issues the first weight loads contains no
+scalar-memory WAIT (the leading arguments arrive preloaded in SGPRs; csrc/dec_kernels.hip "KERNEL ARGUMENTS").
 DESIGN.md section 4; no reference counterpart (the reference's decoder is a CoreML graph)."""
 import os
 import re
@@ -68,7 +68,8 @@ def test_no_scalar_round_trip_in_front_of_the_first_weight_load(gemv_kernels):
         assert first is not None, name
         start = max((i for i in range(first) if ins[i].startswith(("s_cbranch", "s_branch"))), default=0)
         block = ins[start + 1:first]
-        offenders = [s for s in block if s.startswith("s_load") or s.startswith("s_waitcnt lgkmcnt")]
+        # (a scalar load ISSUED early is harmless; what costs the round trip is WAITING for one before the weight loads go out)
+        offenders = [s for s in block if s.startswith("s_waitcnt lgkmcnt")]
         if offenders:
             bad.append((name, offenders[:3]))
     assert not bad, "a kernel-argument fetch sits in front of the first weight load again: %r" % bad[:3]
