@@ -719,25 +719,6 @@ __global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_rows_attn_kernel(
     // nothing of the block can be consumed before all of it was requested (round 5: a re-ordered argument list was enough
     // for the compiler to issue 6 of the 8 loads, start on the scores, and issue the last two afterwards -- 13.7 -> 16.5 us
     // at 8 sequences: the stream is bound by bytes in flight per CU)
-    // The STREAMING shape (NS = 8, block by block: the kernel that carries the roofline) issues the 2 U loads of a block as
-    // inline asm, in program order -- K0 V0 K1 V1 ... -- and waits for them with COUNTED waits inside process_block.
-    // (Loads complete in order, so a count written for these 2 U requests only gets stricter if a load or store of the
-    // compiler's own is in flight beside them; the loaded registers are touched by nothing but the waiting asm before it.)
-    auto stream_block = [&](const bf16_t *kb, const bf16_t *vb, int r0, int clamp, u32x4 (&kv)[U], u32x4 (&vv)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int i = r0 + u * (NS * 8) + stream * 8 + rg;
-            i = i < clamp ? i : clamp;  // clamped: unconditional loads
-            const bf16_t *pk = kb + (long)i * 64, *pv = vb + (long)i * 64;
-            if (NT) {
-                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(kv[u]) : "v"(pk) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(vv[u]) : "v"(pv) : "memory");
-            } else {
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(kv[u]) : "v"(pk) : "memory");
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vv[u]) : "v"(pv) : "memory");
-            }
-        }
-    };
     auto block_fence = [](u32x4 (&kv)[U], u32x4 (&vv)[U]) {
         static_assert(U == 4, "block_fence is written for 4 loads per block");
         asm volatile("" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]));
@@ -755,10 +736,9 @@ __global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_rows_attn_kernel(
         const bf16_t *vb = vc + (long)bh * T_stride * 64 + e8 * 8;
         const f32x4 *qp = (const f32x4 *)(q + (long)b * d + h * 64 + e8 * 8);
         const f32x4 q0 = qp[0], q1 = qp[1];
-        // SPEC: the first block (DEEP: every block) of this stream is requested BEFORE the position / live count is looked
-        // at.  The streaming shape of the cross-attention (NS = 8, block by block) keeps the round-4 loop: its key count is
-        // an argument, its time is the stream, and the compiler's schedule of that loop (all 2 U loads of a block issued
-        // together) is what the 6.4 TB/s were measured with.
+        // SPEC: the first block (DEEP: every block) of this stream is requested BEFORE the position / live count / query is
+        // looked at.  (This kernel serves the self-attention and the flat, deep cross-attention of a few pairs -- the latency
+        // shapes; the streaming cross-attention is dec_xrows_attn_kernel, the round-4 loop.)
         constexpr bool SPEC = SELF || DEEP;
         constexpr int NB = DEEP ? ATT_MAXK / (NS * 8 * U) : 1;
         u32x4 kall[NB][U], vall[NB][U];
@@ -786,23 +766,12 @@ __global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_rows_attn_kernel(
         float m_run = -1e30f, l_run = 0.f;
         float oa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         // one block of U x 8 rows of this stream: scores, block maximum, rescale, accumulate -- the stream's arithmetic
-        // counted: the block was requested by stream_block (inline-asm loads, K and V of row group u are requests 2u and
-        // 2u + 1 of 2 U); the counted wait in front of row group u's score carries the PREVIOUS score through the same asm, so
-        // that score u - 1 is computed before the wave waits for row group u -- scores under the tail of the loads, the
-        // schedule the round-4 build had from the compiler (67.7 us at 56 sequences; a wait for all eight: 69.3)
-        auto process_block = [&](int r0, u32x4 (&kv)[U], u32x4 (&vv)[U], bool counted) {
+        auto process_block = [&](int r0, const u32x4 (&kv)[U], const u32x4 (&vv)[U]) {
             float sc[U];
             float mb = -1e30f;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i = r0 + u * (NS * 8) + stream * 8 + rg;
-                if (counted) {
-                    static_assert(U == 4, "the counted waits are written for 4 row groups per block");
-                    if (u == 0) asm volatile("s_waitcnt vmcnt(7)" : "+v"(kv[0])::"memory");
-                    if (u == 1) asm volatile("s_waitcnt vmcnt(5)" : "+v"(kv[1]), "+v"(mb)::"memory");
-                    if (u == 2) asm volatile("s_waitcnt vmcnt(3)" : "+v"(kv[2]), "+v"(mb)::"memory");
-                    if (u == 3) asm volatile("s_waitcnt vmcnt(1)" : "+v"(kv[3]), "+v"(mb)::"memory");
-                }
                 float a = 0.f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -815,7 +784,6 @@ __global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_rows_attn_kernel(
                 sc[u] = i < n_keys ? a : -1e30f;
                 mb = fmaxf(mb, sc[u]);
             }
-            if (counted) asm volatile("s_waitcnt vmcnt(0)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(mb)::"memory");
             mb = fmaxf(mb, __shfl_xor(mb, 8));
             mb = fmaxf(mb, __shfl_xor(mb, 16));
             mb = fmaxf(mb, __shfl_xor(mb, 32));
@@ -845,22 +813,17 @@ __global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_rows_attn_kernel(
             // was requested above (48 x 16 B per lane); the same block arithmetic in the same order: same bits.
 #pragma unroll
             for (int blk = 0; blk < NB; ++blk)
-                if (blk * (NS * 8 * U) < n_keys) process_block(blk * (NS * 8 * U), kall[blk], vall[blk], false);  // workgroup-uniform
+                if (blk * (NS * 8 * U) < n_keys) process_block(blk * (NS * 8 * U), kall[blk], vall[blk]);  // workgroup-uniform
         } else {
             if (SPEC) {
                 block_fence(kall[0], vall[0]);
-                process_block(0, kall[0], vall[0], false);
+                process_block(0, kall[0], vall[0]);
             }
             for (int r0 = SPEC ? NS * 8 * U : 0; r0 < n_keys; r0 += NS * 8 * U) {  // workgroup-uniform trip count
                 u32x4 kv[U], vv[U];
-                if (SPEC) {
-                    load_block(kb, vb, r0, n_keys - 1, kv, vv);
-                    block_fence(kv, vv);
-                    process_block(r0, kv, vv, false);
-                } else {
-                    stream_block(kb, vb, r0, n_keys - 1, kv, vv);
-                    process_block(r0, kv, vv, true);
-                }
+                load_block(kb, vb, r0, n_keys - 1, kv, vv);
+                block_fence(kv, vv);
+                process_block(r0, kv, vv);
             }
         }
 #pragma unroll
@@ -1839,10 +1802,10 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
             // a cache of <= 3.2 MB per layer (tiny.en / base, single chunk) stays in the L2s from one position to the next
             // when it is read with cacheable loads: -1 .. -2 % per position there; +5 % at `small` (4.6 MB): the rule
             else if ((size_t)B * H * T_stride * 64 * 2 * 2 <= (size_t)3200 * 1024)
-                dec_xrows_attn_kernel<8, 4, false, true><<<g, wpw * 64, 0, ctx->stream>>>(
+                dec_rows_attn_kernel<8, 4, false, true><<<g, wpw * 64, 0, ctx->stream>>>(
                     q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
             else
-                dec_xrows_attn_kernel<8, 4, WM_XATTN_NT, true><<<g, wpw * 64, 0, ctx->stream>>>(
+                dec_rows_attn_kernel<8, 4, WM_XATTN_NT, true><<<g, wpw * 64, 0, ctx->stream>>>(
                     q, kc, vc, pos_ptr, live_rows, pA, pB, pC, cold);
         } else {
             dim3 grid(gx, nsplit);
