@@ -60,6 +60,8 @@ def algorithmic_work(family, dims, B):
         return "hbm", 2.0 * gemv[family]                      # bf16 weights streamed once
     if family == "dec_attn_cross":
         return "hbm", B * 2.0 * 1500 * d * 2                  # cached K and V of one layer
+    if family == "dec_attn_cross_fq":
+        return "hbm", B * 2.0 * 1500 * d * 2 + 2.0 * d * d    # ... + the query projection's weights (fused launch, 5 .. 12 chunks)
     if family == "dec_attn_self":
         return "hbm", B * 2.0 * 112 * d * 2                   # mean context ~ 224/2 positions
     flops = {"gemm_qkv_enc": 2.0 * M * 3 * d * d, "gemm_gelu_bf16": 2.0 * M * 4 * d * d,

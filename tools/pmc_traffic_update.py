@@ -4,7 +4,7 @@ sha256 of the kernel source it was taken on (bench.py reports `traffic: null` wh
 
     python tools/pmc_traffic_update.py <pmc summary .txt of tools/rocprof_pmc_summary.py> <model> <group chunks> [source note]
 
-Kernel name -> family: dec_rows_attn_kernel<8,..> = dec_attn_cross, <4,..> = dec_attn_self."""
+Kernel name -> family: dec_xrows_attn_kernel<8,..> (rounds 1-4: dec_rows_attn_kernel<8,..>) = dec_attn_cross, dec_rows_attn_kernel<4,..> = dec_attn_self."""
 import json
 import os
 import re
@@ -16,7 +16,7 @@ from bench import family_source_sha256  # noqa: E402
 
 
 def family_of(kernel):
-    if "dec_rows_attn_kernelILi8" in kernel:
+    if "dec_xrows_attn_kernelILi8" in kernel or "dec_rows_attn_kernelILi8" in kernel:   # (round 5: the cross family's own kernel)
         return "dec_attn_cross"
     if "dec_rows_attn_kernelILi4" in kernel:
         return "dec_attn_self"
