@@ -1279,30 +1279,53 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
     // ties its use to the first of them): the round-4 kernel waited for it before issuing a single load
     const int pos_raw = *(pos_ptr ? pos_ptr : (const int *)tilemax);
     int pos = 0;
-    const int bw = blockIdx.x * 16;  // this workgroup's rows: one per wave
-    for (int b = bw + wave; b < B && b < bw + 16; b += 16) {  // wave-uniform, at most one trip
-        const unsigned long long *row = tilemax + (long)b * n_tiles;
+    const int bw = blockIdx.x * 16;  // this workgroup's rows: one per wave (the row's OWNER: wave r owns row bw + r)
+    // Round 5: the waves that own no row HELP.  A row's 3 242 per-tile keys were one wave's work -- seven dependent round
+    // trips of 8 x 64 keys (one sequence: 15 of the 16 waves idle, ~5 us of the step's tail) -- now the row's P = 1 +
+    // (16 - rows) / rows participants take a contiguous share each (one sequence: 16 x 203 keys = ONE trip) and the owner
+    // takes the maximum of their partial maxima (a maximum: any order, same bits).
+    __shared__ unsigned long long part_s[16][16];
+    const int nrows = B - bw < 16 ? B - bw : 16;
+    const int hpr = (16 - nrows) / nrows;                 // helpers per row
+    const int P = 1 + hpr;
+    int my_row = -1, my_pi = 0;                           // the row this wave scans for, and its participant index
+    if (wave < nrows) { my_row = wave; }
+    else if (wave - nrows < hpr * nrows) { my_row = (wave - nrows) % nrows; my_pi = 1 + (wave - nrows) / nrows; }
+    if (my_row >= 0) {  // wave-uniform
+        const unsigned long long *row = tilemax + (long)(bw + my_row) * n_tiles;
+        const int chunk = (n_tiles + P - 1) / P, t_lo = my_pi * chunk, t_hi = t_lo + chunk < n_tiles ? t_lo + chunk : n_tiles;
         unsigned long long key = 0ull;
-        for (int t0 = lane; t0 < n_tiles; t0 += 64 * 8) {
+        for (int t0 = t_lo + lane; t0 < t_hi; t0 += 64 * 8) {
             unsigned long long k[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int t = t0 + 64 * u;
-                k[u] = row[t < n_tiles ? t : t0];  // clamped: duplicates do not change a max
+                k[u] = row[t < t_hi ? t : t0];  // clamped: duplicates do not change a max
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) key = k[u] > key ? k[u] : key;
-        }
-        {
-            int pv = pos_raw;
-            asm volatile("" : "+s"(pv) : "v"((unsigned)key));
-            pos = pos_ptr ? pv : 0;
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned long long ok = __shfl_xor(key, o);
             key = ok > key ? ok : key;
         }
+        if (lane == 0) part_s[my_row][my_pi] = key;
+    }
+    __syncthreads();
+    for (int b = bw + wave; b < B && b < bw + 16; b += 16) {  // wave-uniform, at most one trip: the owners
+        unsigned long long key = lane < P ? part_s[wave][lane] : 0ull;
+        {
+            int pv = pos_raw;
+            asm volatile("" : "+s"(pv) : "v"((unsigned)key));
+            pos = pos_ptr ? pv : 0;
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {   // P <= 16 partial maxima in lanes 0 .. 15
+            const unsigned long long ok = __shfl_xor(key, o);
+            key = ok > key ? ok : key;
+        }
+        key = __shfl(key, 0);               // (every lane of the owner carries the row's key, as before)
         if (ts.rng) {
             // `key` is the best allowed TEXT token.  Merge the timestamp tiles: best allowed timestamp and
             // log-sum-exp of the allowed timestamps; a timestamp is forced when that exceeds the best text logit
