@@ -9,10 +9,15 @@
 //     activations likewise; everything is requested up front (one memory round trip); LayerNorm is FOLDED into the
 //     weights (W' = W gamma) with the row statistics arriving as deterministic partial sums from the producer of the
 //     residual; bias, GELU, residual add (+ bf16 copy + next statistics), KV-cache append and the logits arg-max with the
-//     suppress bitmaps / timestamp rules are fused epilogues, so a decoder layer is 8 launches.
-//   * dec_rows_attn_kernel: single-query attention over a bf16 K/V cache as NS canonical row streams per (sequence,
-//     head) pair (8 cross, 4 self), 8 lanes per 128-byte row, fp32 online softmax per stream, one ordered merge -- the
-//     same arithmetic whatever the launch shape.  With early stop on it walks the compact list of LIVE rows.
+//     suppress bitmaps / timestamp rules are fused epilogues, so a decoder layer is 8 launches.  Round 5: the scalars a
+//     kernel's first loads need are LEADING scalar arguments, preloaded into SGPRs (no kernel-argument fetch in front of
+//     the first weight load: tests/test_isa_cpu.py); the residual epilogue is finished by four waves per unit.
+//   * dec_xrows_attn_kernel (cross, streaming / flat) and dec_rows_attn_kernel (self; flat deep cross): single-query
+//     attention over a bf16 K/V cache as NS canonical row streams per (sequence, head) pair (8 cross, 4 self), 8 lanes per
+//     128-byte row, fp32 online softmax per stream, one ordered merge -- the same arithmetic whatever the launch shape.
+//     With early stop on they walk the compact list of LIVE rows.
+//   * dec_xattn_fq_kernel: cross_attn_ln + query projection INSIDE the cross-attention launch for 96 .. 256 pairs alone on
+//     the device (7 launches per layer), bit-identical to the two launches.
 //   * argmax_embed_kernel: closes a position (arg-max reduce, timestamp decision, early-stop flags + live list, next
 //     token, next embedding + statistics) and advances the decode position, which lives in HBM (*pos_ptr) -- so ONE
 //     captured hipGraph of the whole position (and one of WM_BURST positions) replays for every position.
