@@ -80,6 +80,9 @@ WM_API int wmdbg_set_precision(wm_ctx *ctx, int precision);
  * "gemm_gm", "no_early_stop", "xattn_no_deep", "xattn_never_short", "logits_tn", "enc_attn_mfma_sum"; key "reset" restores the product's rules.  Process-wide.  The PRODUCT library has no such
  * entry point and reads no environment variable for launch shapes (rounds 1-3 had WM_GEMV_*, WM_XATTN_*, WM_GEMM_*). */
 WM_API int wmdbg_set_tuning(const char *key, int value);
+/* The product's group policy as a pure function: decode groups of a wm_transcribe_greedy call of B chunks with `lanes` lanes
+ * available; explicit_lanes != 0: the host set the lane count with wm_set_lanes (host only, no GPU). */
+WM_API int wmdbg_group_count(int B, int lanes, int explicit_lanes);
 
 #ifdef __cplusplus
 }

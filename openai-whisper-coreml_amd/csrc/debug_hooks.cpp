@@ -34,6 +34,8 @@ extern "C" int wmdbg_set_tuning(const char *key, int value) {
     return WM_ERR_INVALID;
 }
 
+extern "C" int wmdbg_group_count(int B, int lanes, int explicit_lanes) { return wm_group_count(B, lanes, explicit_lanes != 0, 0); }
+
 extern "C" int wmdbg_mel_filterbank(int n_mels, float *out) {
     WM_REQUIRE(out && n_mels > 0 && n_mels <= 256, WM_ERR_INVALID, "bad args");
     std::vector<float> f;

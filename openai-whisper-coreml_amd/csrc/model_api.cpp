@@ -532,6 +532,27 @@ int lane_burst(LaneJob &j, int n_prompt, int n_steps, bool use_graph, bool stop_
 }
 }  // namespace
 
+// Decode groups of a call of B chunks on at most L lanes (pure: tests/test_abi.py pins the table through the debug library).
+// explicit_lanes: the host set a lane count (wm_set_lanes n > 0); gc_probe: the debug knob group_chunks (0 in the product).
+// More groups than lanes run in rounds of the lanes; a group never exceeds WM_DEC_MAXB rows.
+int wm_group_count(int B, int L, bool explicit_lanes, int gc_probe) {
+    if (L < 1) L = 1;
+    int G;
+    const int gc = gc_probe > 0 ? gc_probe : kGroupChunks;
+    if (!explicit_lanes && gc_probe == 0 && B < 144) {
+        G = B < 32 ? 1 : 2;       // the measured policy (comment in wm_transcribe_greedy)
+        if (G > L) G = L;
+    } else if (B <= gc * L) {
+        G = (B + gc - 1) / gc;    // the rounds-1-4 rule: groups of ~gc while there is a lane for each
+    } else {
+        G = (B + WM_DEC_MAXB - 1) / WM_DEC_MAXB;
+        if (G < L) G = L;
+        G = (G + L - 1) / L * L;
+    }
+    const int g_min = (B + WM_DEC_MAXB - 1) / WM_DEC_MAXB;   // (one lane, 129 .. 143 chunks: still two groups)
+    return G < g_min ? g_min : (G < 1 ? 1 : G);
+}
+
 extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int B,
                                     const int32_t *prompt, int n_prompt, int max_new, int32_t eot,
                                     int32_t *tokens_out, int32_t *lens_out, wm_mem mem) try {
@@ -572,18 +593,7 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
     // 8 chunks for each -- the rounds-1-4 rule, and what keeps the lanes under test at small sizes.
     const bool explicit_lanes = ctx->max_lanes > 0;
     const int L = ctx->prof.on ? 1 : (explicit_lanes ? ctx->max_lanes : lane_limit());
-    int G;
-    const int gc = g_wm_tuning.group_chunks > 0 ? g_wm_tuning.group_chunks : kGroupChunks;   // (probes only; 0 in the product)
-    if (!explicit_lanes && g_wm_tuning.group_chunks == 0 && B < 144) {
-        G = B < 32 ? 1 : 2;
-        if (G > L) G = L;
-    } else if (B <= gc * L) {
-        G = (B + gc - 1) / gc;
-    } else {
-        G = (B + WM_DEC_MAXB - 1) / WM_DEC_MAXB;
-        if (G < L) G = L;
-        G = (G + L - 1) / L * L;
-    }
+    const int G = wm_group_count(B, L, explicit_lanes, g_wm_tuning.group_chunks);
     const int n_lanes = G < L ? G : L;
     while ((int)ctx->lanes.size() < n_lanes - 1) {
         wm_ctx *c = nullptr;

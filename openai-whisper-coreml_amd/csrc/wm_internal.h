@@ -149,6 +149,7 @@ struct wm_ctx {
 };
 
 int wm_ctx_make_current(const wm_ctx *ctx);
+int wm_group_count(int B, int L, bool explicit_lanes, int gc_probe);   // model_api.cpp: decode groups of a wm_transcribe_greedy call
 
 // ---------------------------------------------------------------- launch-shape experiment knobs
 // Launch shapes are chosen by fixed rules (dec_kernels.hip pick_shape / wm_dec_attn_splits, gemm.hip wm_gemm): the

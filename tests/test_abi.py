@@ -133,3 +133,24 @@ def test_multi_host_helpers_reject_bad_sizes(pkg):
     assert lib.wm_multi_unpack_tokens(p, 2, 2, 3, 5, p, p) == 1          # more chunks than world_size * per rows
     lo, hi = ctypes.c_int(), ctypes.c_int()
     assert lib.wm_multi_partition(120, 8, 3, ctypes.byref(lo), ctypes.byref(hi)) == 0 and (lo.value, hi.value) == (45, 60)
+
+
+def test_group_policy_of_a_call(pkg):
+    """wm_transcribe_greedy's decode groups (model_api.cpp wm_group_count, measured in round 5: profiles/r05_group_policy.txt):
+    the library's own policy -- one group below 32 chunks, two up to 143, three from 144, never a group above 128 rows, never
+    more groups in flight than lanes -- and the rounds-1-4 rule when the host sets a lane count."""
+    lib = pkg.binding.load_debug_library()
+    g = lambda B, lanes, explicit=0: lib.wmdbg_group_count(B, lanes, explicit)
+    assert [g(B, 3) for B in (1, 8, 15, 24, 31)] == [1] * 5
+    assert [g(B, 3) for B in (32, 48, 64, 96, 128, 143)] == [2] * 6
+    assert [g(B, 3) for B in (144, 160, 288, 384)] == [3] * 4 and g(385, 3) == 6            # whole rounds of the lanes
+    assert g(100, 1) == 1 and g(130, 1) == 2 and g(143, 1) == 2 and g(300, 1) == 3         # one lane: groups of <= 128 in turn
+    assert g(64, 2) == 2 and g(200, 2) == 2 and g(257, 2) == 4
+    # an explicit lane count: groups of ~8 while there is a lane for each, then balanced groups of <= 128
+    assert [g(B, 3, 1) for B in (1, 8, 9, 15, 19, 24)] == [1, 1, 2, 2, 3, 3]
+    assert g(25, 3, 1) == 3 and g(52, 3, 1) == 3 and g(400, 3, 1) == 6
+    for B in range(1, 600, 7):
+        for lanes in (1, 2, 3, 4, 8):
+            for ex in (0, 1):
+                G = g(B, lanes, ex)
+                assert G >= 1 and -(-B // G) <= 128, (B, lanes, ex, G)
