@@ -1276,7 +1276,7 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
                                                              float *__restrict__ x, bf16_t *__restrict__ xb,
                                                              float *__restrict__ stats_out, WmTsDev ts,
                                                              int *__restrict__ arrive, int fallback_tok,
-                                                             float *__restrict__ mean_buf, WmStopDev stop) {
+                                                             float *__restrict__ mean_buf, WmStopDev stop, int rpw) {
     __shared__ int tok_s[16];
     __shared__ int is_last_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1284,13 +1284,13 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
     // ties its use to the first of them): the round-4 kernel waited for it before issuing a single load
     const int pos_raw = *(pos_ptr ? pos_ptr : (const int *)tilemax);
     int pos = 0;
-    const int bw = blockIdx.x * 16;  // this workgroup's rows: one per wave (the row's OWNER: wave r owns row bw + r)
+    const int bw = blockIdx.x * rpw;  // this workgroup's rows (rpw <= 16): one per wave (the row's OWNER: wave r owns row bw + r)
     // Round 5: the waves that own no row HELP.  A row's 3 242 per-tile keys were one wave's work -- seven dependent round
     // trips of 8 x 64 keys (one sequence: 15 of the 16 waves idle, ~5 us of the step's tail) -- now the row's P = 1 +
     // (16 - rows) / rows participants take a contiguous share each (one sequence: 16 x 203 keys = ONE trip) and the owner
     // takes the maximum of their partial maxima (a maximum: any order, same bits).
     __shared__ unsigned long long part_s[16][16];
-    const int nrows = B - bw < 16 ? B - bw : 16;
+    const int nrows = B - bw < rpw ? B - bw : rpw;
     const int hpr = (16 - nrows) / nrows;                 // helpers per row
     const int P = 1 + hpr;
     int my_row = -1, my_pi = 0;                           // the row this wave scans for, and its participant index
@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
         if (lane == 0) part_s[my_row][my_pi] = key;
     }
     __syncthreads();
-    for (int b = bw + wave; b < B && b < bw + 16; b += 16) {  // wave-uniform, at most one trip: the owners
+    for (int b = bw + wave; b < B && b < bw + nrows; b += 16) {  // wave-uniform, at most one trip: the owners
         unsigned long long key = lane < P ? part_s[wave][lane] : 0ull;
         {
             int pv = pos_raw;
@@ -1410,7 +1410,7 @@ __global__ __launch_bounds__(1024) void argmax_embed_kernel(const unsigned long 
         pos = pos_ptr ? pv : 0;
     }
     if (x && pos + 1 < n_ctx) {
-        for (int b = bw + wave; b < B && b < bw + 16; b += 16) {
+        for (int b = bw + wave; b < B && b < bw + nrows; b += 16) {
             const long tok = tok_s[b - bw];
             float s1 = 0.f, s2 = 0.f;
             // the row stays in registers between the sums and the mean-centred bf16 copy (the first 512 columns: 8 values per lane; the
@@ -1947,12 +1947,18 @@ int wm_argmax_embed(wm_ctx *ctx, const unsigned long long *tilemax, int n_tiles,
     WmStopDev sp;
     memset(&sp, 0, sizeof(sp));
     if (stop) sp = *stop;
-    const int grid = arrive ? (B + 15) / 16 : 1;
-    WM_REQUIRE(grid == 1 || B <= 16 * grid, WM_ERR_INVALID, "argmax_embed: bad grid");
+    // Rows per workgroup.  A row's 3 242 keys (26 KB) are what the kernel pulls, and ONE CU pulls ~25 GB/s: a workgroup per
+    // row (all 16 waves on its keys, one trip) instead of a workgroup per 16 rows -- in situ at 56 rows 37.5 -> 23.2 us,
+    // driver command +0.7 %, tiny.en x 8 -1.6 % per position (profiles/r05_latency_probe.txt, run Q).  With early stop on,
+    // several workgroups cost two agent-scope fences for the live list, so a group of <= 16 rows stays on one workgroup there.
+    int rpw = (arrive && (B > 16 || !sp.done)) ? 1 : 16;
+    if (arrive && g_wm_tuning.argmax_rows_per_wg >= 1 && g_wm_tuning.argmax_rows_per_wg <= 16) rpw = g_wm_tuning.argmax_rows_per_wg;   // (probes)
+    const int grid = arrive ? (B + rpw - 1) / rpw : 1;
+    WM_REQUIRE(grid == 1 || B <= rpw * grid, WM_ERR_INVALID, "argmax_embed: bad grid");
     WM_REQUIRE(arrive || B <= 16, WM_ERR_INVALID, "argmax_embed: more than 16 rows need the arrival counter");
     argmax_embed_kernel<<<grid, 1024, 0, ctx->stream>>>(tilemax, n_tiles, B, seq, pos_ptr, n_prompt, result, arg_first,
                                                         emb, pemb, d, n_ctx, x, xb, stats_out, t, arrive, fallback_tok,
-                                                        mean_buf, sp);
+                                                        mean_buf, sp, rpw);
     WM_HIP(hipGetLastError());
     return WM_OK;
 }

@@ -176,6 +176,7 @@ struct WmTuning {
     int xattn_no_deep = 0;        // 1: the flat (few-pair) cross-attention walks its blocks one round trip at a time
     int xattn_pair_wg_max_pairs = 0;  // EXPERIMENT (lost, same file): alone, 257 .. this many pairs: one cross-attention workgroup per pair, two per CU
     int xattn_fuse_q = 1;         // 96 .. 256 pairs, alone: query projection fused into the cross-attention launch (0: two launches)
+    int argmax_rows_per_wg = 0;   // PROBE: rows per workgroup of the step-closing arg-max (0 = the product's rule: 1, or 16 for <= 16 rows with early stop)
     int group_chunks = 0;         // preferred decode-group size of a wm_transcribe_greedy call (product rule: model_api.cpp)
 };
 extern WmTuning g_wm_tuning;   // api.cpp

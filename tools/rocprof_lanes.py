@@ -11,7 +11,7 @@ import numpy as np
 
 
 def short(n):
-    m = re.search(r"(dec_gemv_kernelILi\d+ELi\dELi\dELi\dELb\d|dec_rows_attn_kernelILi\dELi\dELb\d|gemm256_bf16_kernelILi\d|"
+    m = re.search(r"(dec_gemv_kernelILi\d+ELi\dELi\dELi\dELb\d|dec_x?rows_attn_kernelILi\dELi\dELb\d|dec_xattn_fq_kernel|gemm256_bf16_kernelILi\d|"
                   r"gemm_bf16_kernelILi\d|enc_attn_kernel|layernorm_kernel|argmax_embed_kernel|dec_\w+?_kernel|logmel_stage\d)", n)
     return m.group(1) if m else n[:40]
 
@@ -26,7 +26,7 @@ def main():
     streams = sorted({r[1] for r in rows})
     # decode window: from the last stream's first cross-attention launch of its LAST decode phase to the first stream's last one
     dec = [(short(n), s, a, b) for n, s, a, b in rows]
-    is_x = lambda n: n.startswith("dec_rows_attn_kernelILi8")
+    is_x = lambda n: n.startswith(("dec_xrows_attn_kernelILi8", "dec_rows_attn_kernelILi8", "dec_xattn_fq_kernel"))   # (rounds 1-4: dec_rows_...)
     per = {s: [(a, b) for n, ss, a, b in dec if ss == s and is_x(n)] for s in streams}
     per = {s: v for s, v in per.items() if len(v) > 100}
     # split each stream's cross-attention launches into phases (gap > 5 ms = an encoder in between)
