@@ -19,7 +19,7 @@ extern "C" int wmdbg_set_gemm_tile(int tile) { return wm_gemm_set_tile_override(
 extern "C" int wmdbg_set_tuning(const char *key, int value) {
     WM_REQUIRE(key, WM_ERR_INVALID, "wmdbg_set_tuning: null key");
     struct { const char *name; int *field; } table[] = {
-        {"gemv_tn", &g_wm_tuning.gemv_tn}, {"gemv_nblk", &g_wm_tuning.gemv_nblk}, {"gemv_no_ppw2", &g_wm_tuning.gemv_no_ppw2},
+        {"gemv_tn", &g_wm_tuning.gemv_tn}, {"gemv_nblk", &g_wm_tuning.gemv_nblk}, {"gemv_no_ppw2", &g_wm_tuning.gemv_no_ppw2}, {"gemv_ppw2_nblk", &g_wm_tuning.gemv_ppw2_nblk},
         {"prefetch_max_b", &g_wm_tuning.prefetch_max_b}, {"xattn_split_below", &g_wm_tuning.xattn_split_below},
         {"xattn_wgs", &g_wm_tuning.xattn_wgs}, {"xattn_no_flat", &g_wm_tuning.xattn_no_flat},
         {"xattn_lds_pad", &g_wm_tuning.xattn_lds_pad}, {"xattn_splits", &g_wm_tuning.xattn_splits},

@@ -1559,9 +1559,15 @@ int launch_gemv_shape(wm_ctx *ctx, const DecGemvDev &p, int tn, int nblk, int nw
     hipStream_t s = ctx->stream;
     if (ppw == 2) {  // 16 K parts on 8 waves (the K = 4d residual products at more than one batch block)
         constexpr bool TWO = !LN && EPI == DE_RESID && SPW >= 6 && SPW <= 10;
-        if (!TWO || tn != 1 || nblk != 1 || nw % 2) { wm_set_error("dec_gemv: no two-part kernel for this shape"); return WM_ERR_INVALID; }
+        if (!TWO || tn != 1 || nblk < 1 || nblk > 2 || nw % 2) { wm_set_error("dec_gemv: no two-part kernel for this shape"); return WM_ERR_INVALID; }
         const int w2 = nw / 2;
-        const size_t lds2 = (size_t)nw * 1024 + (size_t)w2 * 32 * 4;
+        const size_t lds2 = (size_t)nw * nblk * 1024 + (size_t)w2 * 32 * 4;
+        if (nblk == 2) {   // two batch blocks per workgroup: a weight fragment feeds two products (w2 == 8: four waves per unit)
+            if (w2 != 8) { wm_set_error("dec_gemv: the two-block two-part kernel needs 8 waves"); return WM_ERR_INVALID; }
+            dec_gemv_kernel<TWO ? SPW : 6, 1, 2, TWO ? EPI : DE_RESID, TWO ? LN : false, 2, 4><<<grid, w2 * 64, lds2, s>>>(GEMV_ARGS(p));
+            WM_HIP(hipGetLastError());
+            return WM_OK;
+        }
         // (row split, see the kernel: four waves per unit finish the residual epilogue; w2 >= 4 and more than one sequence)
         if (w2 >= 4 && p.B > 1)
             dec_gemv_kernel<TWO ? SPW : 6, 1, 1, TWO ? EPI : DE_RESID, TWO ? LN : false, 2, 4><<<grid, w2 * 64, lds2, s>>>(GEMV_ARGS(p));
@@ -1659,7 +1665,9 @@ static void pick_shape(int epi, bool ln, int spw, int nw, int B, int n_tiles, in
     // Tile-group width by RESIDENCY ROUNDS: an 8-wave workgroup of the (1, 2) shape needs <= 128 VGPRs and sits two per
     // CU, the wide shapes (136-190 VGPRs) one per CU; a grid that needs a second round of the chip costs a whole kernel
     // time (measured: fc1 at 56 rows as 320 one-per-CU workgroups = two rounds), so: fewest rounds first, then the
-    // narrowest group that still leaves >= 192 workgroups, else the widest.
+    // narrowest group that still leaves >= 192 workgroups, else the widest.  (Groups of THREE tiles -- fc1 of d = 1280 at
+    // 49 .. 64 rows as 214 workgroups of 162 VGPRs instead of 160 of 186 -- were built in round 5 and cost the three-lane
+    // run 2 %: 2078 vs 2114-2125 audio-s/s, NOTEBOOK round 5.)
     const int g = (blocks + 1) / 2;
     int best = 1, best_rounds = 1 << 30, best_wgs = 0;
     for (int t = 1; t <= 4; t *= 2) {
@@ -1705,6 +1713,20 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     const bool no_ppw = g_wm_tuning.gemv_no_ppw2 != 0;
     const int ppw = (!no_ppw && !ln && a.epi == DE_RESID && nw == 16 && a.B > 16 && spw >= 6 && spw <= 10 && tn == 1 &&
                      nblk == 1) ? 2 : 1;
+    if (ppw == 2) {
+        // ... and TWO batch blocks per workgroup (a weight fragment feeds two products; 144 VGPRs at spw 10: one workgroup per
+        // CU) when the one-block grid would not fit one workgroup per CU but the two-block grid does: 1.25 workgroups per CU
+        // run at the pace of the CUs that hold two.  Measured alone, d = 1280: 53 .. 96 rows 12.2 -> 9.9 us, 128 rows (640
+        // two-per-CU vs 320 one-per-CU workgroups) 15.5 vs 16.7: the rule; d = 768 / 1024 at 96 / 128 rows: 5.9 -> 5.8 / 8.7 -> 8.1
+        // (profiles/r05_fc2_two_blocks.txt).  Same parts, same order of the sums: same bits.
+        const int blocks = (a.B + 15) / 16;
+        const int knob = g_wm_tuning.gemv_ppw2_nblk;   // probes: 1 / 2 force the shape
+        const bool two = knob ? knob == 2 : (p.n_tiles * blocks > 256 && p.n_tiles * ((blocks + 1) / 2) <= 256);
+        if (two) {
+            nblk = 2;
+            p.bgroups = (blocks + 1) / 2;
+        }
+    }
     p.n_tg = (p.n_tiles + tn - 1) / tn;
     p.n_tg_pad = p.bgroups > 1 ? (p.n_tg + 7) / 8 * 8 : p.n_tg;  // (tile group, batch group) decode needs rows of 8
     int grid = p.n_tg_pad * p.bgroups;

@@ -160,6 +160,7 @@ int wm_group_count(int B, int L, bool explicit_lanes, int gc_probe);   // model_
 struct WmTuning {
     int gemv_tn = 0;              // force tiles per workgroup of the wide decode GEMVs (1, 2, 4)
     int gemv_nblk = 0;            // 1: one batch block per workgroup also above 16 rows
+    int gemv_ppw2_nblk = 0;       // probes: 1 / 2 = force one / two batch blocks per workgroup in the two-parts-per-wave K = 4d residual product (0: the rule)
     int gemv_no_ppw2 = 0;         // 1: K = 4d residual product as 16-wave workgroups (no two-parts-per-wave kernel)
     int prefetch_max_b = 16;      // L2 warm-up workgroups up to this decode-group size (0: never)
     int xattn_split_below = 96;   // (sequence, head) pairs below which the cross-attention streams are dealt flat

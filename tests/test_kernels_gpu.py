@@ -155,7 +155,9 @@ def test_decode_gemv(ctx, B, N, K, ln):
 
 
 @pytest.mark.parametrize("B,N,K", [(8, 768, 3072), (17, 768, 3072), (32, 768, 3072), (17, 1024, 4096), (32, 1024, 4096),
-                                   (56, 1280, 5120), (17, 768, 768), (40, 1024, 1024), (33, 512, 2048), (128, 384, 1536)])
+                                   (56, 1280, 5120), (17, 768, 768), (40, 1024, 1024), (33, 512, 2048), (128, 384, 1536),
+                                   # two batch blocks per workgroup in the two-parts-per-wave kernel (and the sizes either side)
+                                   (72, 1280, 5120), (90, 1280, 5120), (128, 1280, 5120), (96, 768, 3072), (128, 1024, 4096)])
 def test_decode_gemv_residual_at_every_width_and_group_size(ctx, B, N, K):
     """the fc2 product (K = 4d) splits K over 16 waves at d = 768 / 1024 / 1280; above one batch block
     the two-parts-per-wave kernel serves it.  At d = 768 / 1024 the launch-shape choice used to contradict it
@@ -182,6 +184,10 @@ def test_decode_gemv_residual_at_every_width_and_group_size(ctx, B, N, K):
     assert ctx.lib.wmdbg_dec_gemv_resid(ctx.handle, P(x[:1].copy()), P(Wt), P(bias), P(one), P(cp[:1].copy()),
                                         P(stt[:1].copy()), 1, N, K) == 0
     assert np.array_equal(one[0], res[0])
+    last = r0[B - 1:B].copy()   # ... and the last row (the second block of a two-block workgroup, a partly filled block)
+    assert ctx.lib.wmdbg_dec_gemv_resid(ctx.handle, P(x[B - 1:B].copy()), P(Wt), P(bias), P(last), P(cp[:1].copy()),
+                                        P(stt[:1].copy()), 1, N, K) == 0
+    assert np.array_equal(last[0], res[B - 1])
 
 
 @pytest.mark.parametrize("B,H,T,n_keys,nsplit", [(2, 2, 448, 1, 1), (2, 2, 448, 37, 1), (1, 3, 448, 448, 1),

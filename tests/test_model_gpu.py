@@ -963,7 +963,7 @@ def test_bit_level_batch_invariance_at_d1280(pkg):
     rng = np.random.default_rng(0)
     tok = rng.integers(0, 51865, size=(n, 3)).astype(np.int32)
     ref1 = ctx.decode_logits(tok[:1], xa[:1])
-    for Bn in (3, 4, 5, 8, 16, 17, 40, 72):
+    for Bn in (3, 4, 5, 8, 16, 17, 40, 56, 72):   # (56 / 72 rows: fc2 as two batch blocks per workgroup, 40: one)
         lg = ctx.decode_logits(tok[:Bn], xa[:Bn])
         assert np.array_equal(lg[0], ref1[0]), "row 0 changed with batch %d" % Bn
         if Bn > 16:
@@ -1303,7 +1303,7 @@ def test_decode_groups_above_sixteen_at_d768_and_d1024(pkg, model, d, heads):
     _, conf = R.detect_language(sd, dims, xa)
     for b in range(7):
         _check_choice(conf[b], int(one[b]))
-    for Bn in (17, 32):
+    for Bn in (17, 32, 96, 128):   # (96 / 128 rows: the fc2 product runs two batch blocks per workgroup at these widths)
         idx = [(3 * i + 2) % 7 for i in range(Bn)]
         assert np.array_equal(ctx.detect_language(xa[idx]), one[idx]), Bn
     prompt = [50258, 50259, 50359, 50363]
