@@ -282,6 +282,50 @@ def frontend_alone(B, pcm16):
                     "(f64), kernel time ~0.1 ms: the call is bound by the host copies and the Python wrapper's buffers"}
 
 
+def build_summary(line):
+    """Compact digest of a bench line, emitted as its LAST key: the driver keeps a 2 000-character tail of
+    the line, and the 25 KB of tables in front used to push every figure a reader needs out of it.  A pure function of
+    the line (CPU-tested on a recorded one); <= 1 500 characters as JSON."""
+    def frac(d, *path):
+        for k in path:
+            d = d.get(k) if isinstance(d, dict) else None
+        return round(d, 4) if isinstance(d, (int, float)) else None
+
+    def r1(v):
+        return round(v, 1) if isinstance(v, (int, float)) else None
+    out = {"value": r1(line.get("value")), "n_gpus": line.get("n_gpus"), "ms_per_step": r1(line.get("ms_per_step")),
+           "value_batch8": r1(line.get("value_batch8")), "single_batch_latency_ms": r1(line.get("single_batch_latency_ms")),
+           "early_stop_value": r1((line.get("early_stop") or {}).get("value")),
+           "tok_per_s": r1(line.get("tok_per_s_end_to_end")),
+           "stage_frac": {k: frac(line, "stage_roofline", k, "frac") for k in ("frontend", "encoder_xkv", "decode")},
+           "step_frac": frac(line, "step_roofline", "frac"),
+           "roofline": {"kernel": (line.get("roofline") or {}).get("kernel"), "frac": frac(line, "roofline", "frac"),
+                        "avg_us": frac(line, "roofline", "avg_us"), "in_situ_frac": frac(line, "roofline", "in_situ", "frac"),
+                        "traffic_over_alg": None},
+           "token_checks": line.get("token_checks"), "distinct_token_rows": [line.get("distinct_token_rows"), line.get("token_rows")],
+           "cpu_baseline": None,
+           "rccl_ranks": line.get("rccl_ranks")}
+    cb = line.get("cpu_baseline") or {}
+    if isinstance(cb.get("value"), (int, float)):
+        out["cpu_baseline"] = {"audio_s_per_s": round(cb["value"], 3), "cores": cb.get("cores")}
+    roof = line.get("roofline") or {}
+    if roof.get("traffic") and roof.get("alg_bytes_per_launch"):
+        out["roofline"]["traffic_over_alg"] = round(roof["traffic"] / roof["alg_bytes_per_launch"], 4)
+    oc = line.get("other_configs") or {}
+    # one number per other configuration: audio-s/s (ms for the reference's own flow), + the step's roofline fraction
+    out["other"] = {}
+    for k, v in oc.items():
+        if not isinstance(v, dict):
+            continue
+        e = [r1(v.get("value")), frac(v, "step_roofline", "frac")] if "step_roofline" in v else r1(v.get("value"))
+        if "stage_roofline" in v:   # one-group entries: + the encoder stage's fraction of the MFMA peak
+            e.append(frac(v, "stage_roofline", "encoder_xkv", "frac"))
+        out["other"][k] = e
+    if isinstance(oc.get("small_lid_reference_flow"), dict) and oc["small_lid_reference_flow"].get("device_resident_ms") is not None:
+        out["other"]["small_lid_device_resident_ms"] = round(oc["small_lid_reference_flow"]["device_resident_ms"], 3)
+    return out
+
+
 def effective_cores():
     """Host cores this process may actually use (affinity mask and cgroup CPU quota)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -418,7 +462,12 @@ def cpu_baseline(ctx, dims, pcm16_chunk, prompt):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="world size: one rank per GPU.  Default: the launcher's WORLD_SIZE when there is one, else 1; an "
+                         "explicit value that disagrees with the launcher is an error; without a launcher N > 1 starts its own ranks")
+    ap.add_argument("--pin-numa", action="store_true",
+                    help="pin this rank's host threads (the lane threads launch microsecond-scale graphs) to the cores of its "
+                         "GPU's NUMA node (sharding.numa_cpus_for_rank); off by default")
     ap.add_argument("--steps", type=int, default=72)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large-v2")
@@ -449,18 +498,18 @@ def main():
     args = ap.parse_args()
 
     # --gpus N decides the world size (it used to be parsed and never used).  Under a launcher
-    # (torch.distributed.run sets WORLD_SIZE) the two must agree; without one, N > 1 starts the N ranks itself.
+    # (torch.distributed.run sets WORLD_SIZE) an EXPLICIT --gpus must agree with it; when --gpus is not given the launcher's
+    # world size is adopted (`torchrun --nproc-per-node 8 bench.py` works); without a launcher, N > 1 starts the N ranks itself.
     env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus is None:
+        args.gpus = int(env_world) if env_world is not None else 1
     if env_world is not None and int(env_world) != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: refusing to report a line whose "
                          "n_gpus would not be what was asked for" % (args.gpus, env_world))
     if env_world is None and args.gpus > 1:
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        # --standalone: torch.distributed.run picks its own free rendezvous port (no bind-then-close race here)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
         sys.stdout.flush()
         os.execv(sys.executable, cmd)   # the ranks' stdout is this process's: rank 0's JSON line comes out as before
 
@@ -473,6 +522,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
+    collective_ranks = None
     use_dist = world > 1 or os.environ.get("WM_BENCH_FORCE_DIST") == "1"
     # WM_BENCH_DIST_BACKEND=gloo: the same N-rank code path with the collectives on the host -- lets a ONE-GPU box run two
     # ranks that share device 0 (RCCL refuses two ranks on one device); the driver's runs use the default, nccl == RCCL.
@@ -492,6 +542,14 @@ def main():
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: the process group has %d ranks, --gpus asked for %d" % (dist.get_world_size(), args.gpus))
         world = dist.get_world_size()   # from here on: what the backend actually initialised
+        # the ranks the COLLECTIVE really spans: a 4-byte all-reduce of ones over the data-path backend (RCCL under nccl),
+        # also at N = 1 under WM_BENCH_FORCE_DIST -- `rccl_ranks` of the line is this sum, not an echo of WORLD_SIZE
+        one = torch.ones(1, dtype=torch.int32)
+        one = one.cuda() if dist_backend == "nccl" else one
+        dist.all_reduce(one)
+        collective_ranks = int(one.item())
+        if collective_ranks != world:
+            raise SystemExit("bench.py: an all-reduce over the process group counted %d ranks, the group reports %d" % (collective_ranks, world))
 
     import importlib
     import openai_whisper_coreml_amd as pkg
@@ -537,6 +595,20 @@ def main():
     # own a HIP stream + KV caches each.  The groups are formed by sharding.plan_groups -- a pure function of
     # (steps, fuse, inflight), identical on every rank -- and the token streams are exchanged ONCE per run with a
     # fixed-stride all-gather (sharding.run_grouped), so the collective never depends on which lane finished first.
+    pinned = None
+    if args.pin_numa:   # before the lane threads exist: they inherit the mask
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            n_dev = ctypes.c_int(0)
+            hip.hipGetDeviceCount(ctypes.byref(n_dev))
+            bdfs = []
+            for i in range(n_dev.value):
+                b = ctypes.create_string_buffer(64)
+                hip.hipDeviceGetPCIBusId(b, 64, i)
+                bdfs.append(b.value.decode())
+            pinned = sharding.pin_to_numa(bdfs, int(os.environ.get("WM_BENCH_LOCAL_DEVICE", local_rank)))
+        except Exception as e:   # placement is an optimisation: never take the run down
+            print("bench.py: --pin-numa failed: %r" % (e,), file=sys.stderr)
     ctxs = [ctx] + [ctx.clone() for _ in range(S - 1)]
     for c in ctxs:
         c.set_lanes(1)   # this harness supplies the concurrency itself (S host threads x one decode group each)
@@ -762,7 +834,7 @@ def main():
         others = other_configs(B, args.model, pcm, max_new)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:   # at N > 1 too: CPU-only, after the timed region; the other ranks wait at the closing barrier
         try:
             cpu = cpu_baseline(ctx, dims, pcm[1], prompt)
         except Exception as e:  # the baseline leg must never take the GPU number down with it
@@ -782,8 +854,11 @@ def main():
             "value": total_audio / dt,
             "unit": "audio-sec/s",
             "n_gpus": world,   # = the ranks of the initialised process group (== --gpus, checked above)
-            "rccl_ranks": (world if dist_backend == "nccl" else 0) if use_dist else None,   # None: single process, no collective
+            # ranks counted by a 4-byte all-reduce over RCCL (0: the collectives ran over gloo; None: single process, no collective)
+            "rccl_ranks": (collective_ranks if dist_backend == "nccl" else 0) if use_dist else None,
+            "collective_ranks": collective_ranks,
             "dist_backend": (dist_backend if use_dist else None),
+            "host_cores_pinned": (len(pinned) if pinned else None),   # --pin-numa: cores of this rank's GPU's NUMA node (rank 0's count)
             "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_steps_run,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if args.total_chunks > 0 else "weak", "vs_baseline": None,
@@ -835,6 +910,7 @@ def main():
                                      "sum_family_ms_per_step": fam_sum},
             "kernel_families": fams,
         }
+        line["summary"] = build_summary(line)   # LAST key: inside the 2 000-character tail the driver keeps
         print(json.dumps(line))
     if use_dist:
         dist.barrier()   # rank 0 ran the instrumented pass / CPU baseline: leave together

@@ -12,6 +12,8 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "wm_internal.h"
 #include "model.h"
 
@@ -89,7 +91,21 @@ int wm_ctx_make_current(const wm_ctx *ctx) {
     return WM_OK;
 }
 
-static int ctx_new(int device, wm_ctx **out) {
+// Bit i of a CU mask enables CU i / 8 of XCD i % 8 (the KFD deals the bits round-robin over the 8 XCCs; measured with the
+// census of tools/cu_mask_lab.hip, profiles/r06_cu_mask_lab.txt): 32 CUs per XCD.
+int wm_cu_mask(int part, int parts, int kind, uint32_t mask[8]) {
+    for (int w = 0; w < 8; ++w) mask[w] = 0;
+    int n = 0;
+    for (int i = 0; i < 256; ++i) {
+        const int xcd = i & 7, cu = i >> 3;
+        const int unit = kind == 1 ? xcd : cu, units = kind == 1 ? 8 : 32;
+        // part p owns the units [p * units / parts, (p + 1) * units / parts)
+        if (unit * parts >= part * units && unit * parts < (part + 1) * units) { mask[i >> 5] |= 1u << (i & 31); ++n; }
+    }
+    return n;
+}
+
+static int ctx_new(int device, wm_ctx **out, int part = 0, int parts = 1) {
     WM_REQUIRE(out != nullptr, WM_ERR_INVALID, "null out pointer");
     *out = nullptr;
     int n = 0;
@@ -102,9 +118,19 @@ static int ctx_new(int device, wm_ctx **out) {
                "device %d is %s; this library contains gfx950 code only", device, prop.gcnArchName);
     wm_ctx *c = new wm_ctx();
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    hipError_t se;
+    if (parts > 1) {   // a lane confined to its part of the chip
+        uint32_t mask[8];
+        c->n_cus = wm_cu_mask(part, parts, g_wm_tuning.lane_mask_kind, mask);
+        c->cu_part = part;
+        c->cu_parts = parts;
+        se = hipExtStreamCreateWithCUMask(&c->stream, 8, mask);
+    } else {
+        se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    }
+    if (se != hipSuccess) {
         delete c;
-        wm_set_error("hipStreamCreate failed");
+        wm_set_error("hipStreamCreate failed: %s", hipGetErrorString(se));
         return WM_ERR_HIP;
     }
     int st = wm_frontend_init(&c->fe, c->stream);
@@ -142,10 +168,26 @@ extern "C" int wm_clone(wm_ctx *parent, wm_ctx **out) try {
     return st;
 } WM_API_CATCH
 
+int wm_clone_part(wm_ctx *parent, int part, int parts, wm_ctx **out) {
+    WM_REQUIRE(parent && out && parent->model, WM_ERR_INVALID, "clone_part: bad arguments");
+    WM_REQUIRE(parts >= 2 && parts <= 3 && part >= 0 && part < parts, WM_ERR_INVALID, "clone_part: part %d of %d", part, parts);
+    WM_TRY(ctx_new(parent->device, out, part, parts));
+    int st = wm_model_clone(*out, parent);
+    if (st != WM_OK) {
+        wm_destroy(*out);
+        *out = nullptr;
+    }
+    return st;
+}
+
 extern "C" void wm_destroy(wm_ctx *ctx) {
     if (!ctx) return;
     for (wm_ctx *lane : ctx->lanes) wm_destroy(lane);  // clones go before the weights they alias
     ctx->lanes.clear();
+    for (auto &v : ctx->part_lanes) {
+        for (wm_ctx *lane : v) wm_destroy(lane);
+        v.clear();
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     wm_model_destroy(ctx);

@@ -348,8 +348,8 @@ __device__ __forceinline__ void gemv_unit_epilogue(const DecGemvDev &p, const Ge
 // round-4 kernel walked FOUR dependent scalar round trips (bgroups -> n_tg -> pf fields -> W, a, K) before its first weight
 // load was even issued, and a scalar load of a fresh dispatch misses the scalar cache (invalidated at the kernel boundary).
 // Now everything on the path to the first weight load is a leading SCALAR parameter: one s_load burst at most, and with
-// -mllvm -amdgpu-kernarg-preload-count=16 (build.py, this file only) the dispatcher places those 16 dwords in SGPRs
-// before the first instruction (a by-value struct is never preloaded).  The cold fields stay in the struct; they are
+// -mllvm -amdgpu-kernarg-preload-count=16 (build.py, this file only: 16 = the upper bound; the GEMV's 14 leading dwords
+// of hot scalars are what fits and is preloaded) the dispatcher places them in SGPRs before the first instruction (a by-value struct is never preloaded).  The cold fields stay in the struct; they are
 // requested in one burst right after the weight / activation loads (GEMV_PIN below).
 #define GEMV_PIN(x) asm volatile("" ::"s"(x))
 template <int SPW, int TN, int NBLK, int EPI, bool LN, int PPW = 1, int RSP = 1>
@@ -373,7 +373,7 @@ __global__ __launch_bounds__((LN || SPW == 12 || TN * NBLK > 1 || PPW > 1) ? 512
     const int tg = G == 1 ? wg : (q / G) * 8 + (wg & 7);
     const int grp = G == 1 ? 0 : q % G;
     if (wg >= p.n_tg_pad * G || tg >= p.n_tg) {  // workgroup-uniform: warm-up workgroups and padding
-        int t = wg - p.n_tg_pad * G;
+        int t = wg - p.n_tg_pad * G;   // (warm-up workgroups exist only when n_tg_pad * G % 8 == 0, wm_dec_gemv: t & 7 == wg & 7, this workgroup's XCD)
         if (p.pf_head_major && t >= 0) {
             // the next launch is the fused query + cross-attention kernel (dec_xattn_fq_kernel): XCD x runs the pairs
             // [x per, (x + 1) per) of the head-major pair list (per = pf_head_major), i.e. a few whole or half heads --
@@ -1052,6 +1052,12 @@ __global__ __launch_bounds__(DEEP ? 256 : NS * 64) void dec_xrows_attn_kernel(
 // head's 164 KB weight slice crosses the fabric once or twice and is an L2 hit for the other sequences of the head; the
 // L2 warm-up workgroups of the previous launch place the tiles the same way (pf_head_major).  (A first version put head h
 // on XCD h % 8: 24 vs 16 workgroups per XCD at 20 heads x 8, and the stream ran at the pace of the fuller XCDs.)
+// "Bit-identical to the two launches" is a statement about LIVE rows.  With early stop on, only workgroups of live pairs get
+// past the `bi >= n_live` return, so (a) the rows' new LayerNorm means (mean_out) are written by the head-0 workgroups of the
+// 16-row blocks that still hold a live row -- a block whose rows are all finished keeps the means of two LayerNorms earlier --
+// and (b) the query itself never reaches HBM (m->dq is not written by the fused launch).  Finished rows' tokens are fixed
+// already (pad_tok) and nothing reads their residual again; tests/test_model_gpu.py checks the fused shape against the two
+// launches with early stop on at 8 rows (one block) and at 24 rows of 8 heads (two blocks, blk > 0).
 struct FqCold {
     const float *c1, *c2, *stats_in, *mean_in;
     float *mean_out;
@@ -1643,7 +1649,7 @@ int wm_dec_gemv_split(int K, int *spw) {
 // 3 groups of 56 chunks: 1978 -> 2007 audio-s/s without).  (g_wm_tuning: probes only, see wm_internal.h.)
 static bool pf_enabled(int B) { return B <= g_wm_tuning.prefetch_max_b; }
 
-static void pick_shape(int epi, bool ln, int spw, int nw, int B, int n_tiles, int *tn, int *nblk) {
+static void pick_shape(int epi, bool ln, int spw, int nw, int B, int n_tiles, int n_cus, int *tn, int *nblk) {
     const int env_tn = g_wm_tuning.gemv_tn, env_nb = g_wm_tuning.gemv_nblk;   // 0 in the product
     const int blocks = (B + 15) / 16;
     *tn = 1;
@@ -1672,9 +1678,10 @@ static void pick_shape(int epi, bool ln, int spw, int nw, int B, int n_tiles, in
     int best = 1, best_rounds = 1 << 30, best_wgs = 0;
     for (int t = 1; t <= 4; t *= 2) {
         const int wgs = ((n_tiles + t - 1) / t) * g;
-        const int cap = 256 * (t == 1 ? 2 : 1);
+        const int cap = n_cus * (t == 1 ? 2 : 1);   // n_cus: 256, or the CUs of a sub-chip lane (wm_ctx::n_cus)
         const int rounds = (wgs + cap - 1) / cap;
-        const bool better = rounds < best_rounds || (rounds == best_rounds && best_wgs >= 192 && wgs >= 192);
+        const int fill = n_cus * 3 / 4;              // "still fills the chip": 192 of 256
+        const bool better = rounds < best_rounds || (rounds == best_rounds && best_wgs >= fill && wgs >= fill);
         if (better) { best = t; best_rounds = rounds; best_wgs = wgs; }
     }
     if (env_tn == 1 || env_tn == 2 || env_tn == 4) best = env_tn;
@@ -1705,7 +1712,7 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
     p.ts = a.ts;
     p.n_tiles = (a.N + 15) / 16;
     int tn = 1, nblk = 1;
-    pick_shape(a.epi, ln, spw, nw, a.B, p.n_tiles, &tn, &nblk);
+    pick_shape(a.epi, ln, spw, nw, a.B, p.n_tiles, ctx->n_cus, &tn, &nblk);
     p.bgroups = ((a.B + 15) / 16 + nblk - 1) / nblk;
     // the 16-part K = 4d residual product at more than one batch block: two parts per wave, 8-wave workgroups (two per
     // CU).  pick_shape keeps every 16-wave split at one (tile, block) unit per workgroup, which is what the two-part
@@ -1721,7 +1728,7 @@ int wm_dec_gemv(wm_ctx *ctx, const DecGemvArgs &a) {
         // (profiles/r05_fc2_two_blocks.txt).  Same parts, same order of the sums: same bits.
         const int blocks = (a.B + 15) / 16;
         const int knob = g_wm_tuning.gemv_ppw2_nblk;   // probes: 1 / 2 force the shape
-        const bool two = knob ? knob == 2 : (p.n_tiles * blocks > 256 && p.n_tiles * ((blocks + 1) / 2) <= 256);
+        const bool two = knob ? knob == 2 : (p.n_tiles * blocks > ctx->n_cus && p.n_tiles * ((blocks + 1) / 2) <= ctx->n_cus);
         if (two) {
             nblk = 2;
             p.bgroups = (blocks + 1) / 2;
@@ -1822,7 +1829,9 @@ int wm_dec_attention(wm_ctx *ctx, const float *q, const bf16_t *kc, const bf16_t
         // persistent shape's 150 workgroups of two pairs each.  Measured: SLOWER (large-v3 x 15: 2.123 vs 2.042 ms per
         // position; large-v2 x 16: 2.097 vs 2.022): sixteen streaming waves per CU do worse than eight
         const bool two_per_cu = !short_lived && B * H > 256 && B * H <= g_wm_tuning.xattn_pair_wg_max_pairs;
-        const int cap = (short_lived || two_per_cu) ? (1 << 30) : (g_wm_tuning.xattn_wgs > 0 ? g_wm_tuning.xattn_wgs : 256);
+        // (a sub-chip lane: one persistent workgroup per CU of ITS part of the chip)
+        const int cap_cus = g_wm_tuning.xattn_wgs > 0 && g_wm_tuning.xattn_wgs < ctx->n_cus ? g_wm_tuning.xattn_wgs : ctx->n_cus;
+        const int cap = (short_lived || two_per_cu) ? (1 << 30) : cap_cus;
         int n_wg = B * H;
         if (n_wg > cap) {
             const int rounds = (n_wg + cap - 1) / cap;

@@ -611,7 +611,8 @@ int wm_model_decode_step(wm_ctx *ctx, int B, bool want_logits, int arg_first, in
         a.stats_in = m->dstats;
         a.mean_in = mean_buf(cur); a.mean_out = mean_buf(cur ^ 1); cur ^= 1;
         if (fuse_q) {
-            // 4 + 5 as ONE launch (the latency shape: every pair's workgroup forms its own query, dec_kernels.hip)
+            // 4 + 5 as ONE launch (the latency shape: every pair's workgroup forms its own query, dec_kernels.hip).  Differs from
+            // the two launches for FINISHED rows only (early stop): their block's means stay stale, m->dq is not written
             WM_TRY(wm_dec_xattn_fq(ctx, a, xk, xv, B, H, S, S, m->datt, live, nlive, L.wxo, d, d));
         } else {
             WM_TRY(wm_dec_gemv(ctx, a));

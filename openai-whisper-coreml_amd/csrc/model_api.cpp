@@ -62,6 +62,8 @@ extern "C" int wm_set_suppress(wm_ctx *ctx, const int32_t *suppress, int n, cons
     (void)m;
     WM_TRY(wm_model_set_suppress(ctx, suppress, n, suppress_first, n_first));
     for (wm_ctx *lane : ctx->lanes) WM_TRY(wm_model_set_suppress(lane, suppress, n, suppress_first, n_first));
+    for (auto &v : ctx->part_lanes)
+        for (wm_ctx *lane : v) WM_TRY(wm_model_set_suppress(lane, suppress, n, suppress_first, n_first));
     return WM_OK;
 } WM_API_CATCH
 extern "C" int wm_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t timestamp_begin, int32_t eot,
@@ -71,6 +73,9 @@ extern "C" int wm_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t timestamp
     WM_TRY(wm_model_set_timestamp_rules(ctx, enable, timestamp_begin, eot, max_initial_timestamp_index));
     for (wm_ctx *lane : ctx->lanes)
         WM_TRY(wm_model_set_timestamp_rules(lane, enable, timestamp_begin, eot, max_initial_timestamp_index));
+    for (auto &v : ctx->part_lanes)
+        for (wm_ctx *lane : v)
+            WM_TRY(wm_model_set_timestamp_rules(lane, enable, timestamp_begin, eot, max_initial_timestamp_index));
     return WM_OK;
 } WM_API_CATCH
 extern "C" int wm_set_lanes(wm_ctx *ctx, int n_lanes) try {
@@ -553,6 +558,19 @@ int wm_group_count(int B, int L, bool explicit_lanes, int gc_probe) {
     return G < g_min ? g_min : (G < 1 ? 1 : G);
 }
 
+// SUB-CHIP LANES (round 6): P = 2 or 3 decode groups of a call, each on its OWN part of the chip -- weight-sharing clones whose
+// streams carry complementary CU masks (wm_clone_part) -- instead of one latency-bound chain (HBM ~70 % idle between 9 and 64
+// chunks at large-v2) or unmasked chains whose every launch floods all 256 CUs.  Returns 0 when the call is served better by
+// the unmasked lanes of wm_group_count.  Measured: profiles/r06_group_policy.txt.  Launch shapes only: same kernels, same bits.
+int wm_lane_parts(int B, int L, bool explicit_lanes, int n_text_state, int n_text_layer) {
+    (void)n_text_state; (void)n_text_layer;
+    const int knob = g_wm_tuning.lane_parts;     // 0 in the product
+    if (knob == 1) return 0;
+    if (knob == 2 || knob == 3) return (B >= 2 * knob && B <= knob * WM_DEC_MAXB) ? knob : 0;
+    if (explicit_lanes || L < 2) return 0;       // a host that sets a lane count gets the lanes it asked for
+    return 0;
+}
+
 extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int B,
                                     const int32_t *prompt, int n_prompt, int max_new, int32_t eot,
                                     int32_t *tokens_out, int32_t *lens_out, wm_mem mem) try {
@@ -593,16 +611,26 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
     // 8 chunks for each -- the rounds-1-4 rule, and what keeps the lanes under test at small sizes.
     const bool explicit_lanes = ctx->max_lanes > 0;
     const int L = ctx->prof.on ? 1 : (explicit_lanes ? ctx->max_lanes : lane_limit());
-    const int G = wm_group_count(B, L, explicit_lanes, g_wm_tuning.group_chunks);
-    const int n_lanes = G < L ? G : L;
-    while ((int)ctx->lanes.size() < n_lanes - 1) {
-        wm_ctx *c = nullptr;
-        WM_TRY(wm_clone(ctx, &c));
-        ctx->lanes.push_back(c);
+    const int parts = ctx->prof.on ? 0 : wm_lane_parts(B, L, explicit_lanes, D.n_text_state, D.n_text_layer);
+    const int G = parts ? parts : wm_group_count(B, L, explicit_lanes, g_wm_tuning.group_chunks);
+    const int n_lanes = parts ? parts : (G < L ? G : L);
+    if (parts) {
+        std::vector<wm_ctx *> &pl = ctx->part_lanes[parts - 2];
+        while ((int)pl.size() < parts) {
+            wm_ctx *c = nullptr;
+            WM_TRY(wm_clone_part(ctx, (int)pl.size(), parts, &c));
+            pl.push_back(c);
+        }
+    } else {
+        while ((int)ctx->lanes.size() < n_lanes - 1) {
+            wm_ctx *c = nullptr;
+            WM_TRY(wm_clone(ctx, &c));
+            ctx->lanes.push_back(c);
+        }
     }
     std::vector<LaneJob> jobs(n_lanes);
     for (int l = 0; l < n_lanes; ++l) {
-        jobs[l].c = l == 0 ? ctx : ctx->lanes[l - 1];
+        jobs[l].c = parts ? ctx->part_lanes[parts - 2][l] : (l == 0 ? ctx : ctx->lanes[l - 1]);
         for (auto &e : jobs[l].ev) WM_HIP(hipEventCreate(&e));
         if (stop.on)
             for (auto &e : jobs[l].burst_ev) WM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -648,7 +676,8 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
                     // does this burst share the chip?  other lanes of this call still decoding, or other calls in flight
                     int busy = 0;
                     for (int o = 0; o < n_lanes; ++o) busy += jobs[o].state == LaneJob::DECODING && jobs[o].t < n_steps && !jobs[o].stopped;
-                    const bool shared = busy > 1 || g_wm_active_decodes[ctx->device & 63].load(std::memory_order_relaxed) > 1;
+                    // (sub-chip lanes own their CUs: the other lanes of THIS call do not make the chip "shared")
+                    const bool shared = (busy > 1 && !parts) || g_wm_active_decodes[ctx->device & 63].load(std::memory_order_relaxed) > 1;
                     WM_TRY(lane_burst(j, n_prompt, n_steps, use_graph, stop.on, shared));
                     progress = true;
                     continue;

@@ -129,3 +129,63 @@ def run_grouped(plan, inflight, run_group, rows_per_step, max_new, dist=None, wo
         assert toks.shape[0] == n_local and lens.shape[0] == n_local, "run_group returned the wrong number of rows"
         gathered = gather_tokens(dist, toks, lens, n_local * world_size, world_size, device=device)
     return results, gathered
+
+
+# ---------------------------------------------------------------------------------- host placement (one process per GPU)
+def _parse_cpulist(text):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def numa_node_of_pci(bdf, sysfs_root="/sys"):
+    """NUMA node of a PCI device ('0000:05:00.0', as hipDeviceGetPCIBusId prints it); None when the platform reports none
+    (-1: single-node boxes, most VMs) or the device is not in sysfs."""
+    import os
+    try:
+        n = int(open(os.path.join(sysfs_root, "bus", "pci", "devices", bdf.lower(), "numa_node")).read().strip())
+    except (OSError, ValueError):
+        return None
+    return n if n >= 0 else None
+
+
+def numa_cpus_for_rank(bdfs, local_rank, allowed=None, sysfs_root="/sys", min_cpus=4):
+    """Cores for rank `local_rank` of a one-process-per-GPU job: the cores of its GPU's NUMA node, split evenly among the
+    ranks whose GPUs sit on the same node (in rank order), intersected with `allowed` (the process's current affinity).
+    bdfs: PCI bus ids of the job's GPUs, indexed by local rank.  Returns a sorted list, or None = "do not pin" (no NUMA
+    information, or the rank's share would be smaller than min_cpus: each rank runs 3 lane threads + the main thread whose
+    whole job is launching microsecond-scale graphs).  A pure function of the files under sysfs_root: CPU-tested with a
+    fake topology."""
+    import os
+    nodes = [numa_node_of_pci(b, sysfs_root) for b in bdfs]
+    mine = nodes[local_rank] if 0 <= local_rank < len(nodes) else None
+    if mine is None:
+        return None
+    try:
+        cpus = _parse_cpulist(open(os.path.join(sysfs_root, "devices", "system", "node", "node%d" % mine, "cpulist")).read())
+    except (OSError, ValueError):
+        return None
+    if allowed is not None:
+        cpus = [c for c in cpus if c in set(allowed)]
+    peers = [r for r, n in enumerate(nodes) if n == mine]
+    k = peers.index(local_rank)
+    per = len(cpus) // len(peers)
+    if per < min_cpus:
+        return sorted(cpus) if len(cpus) >= min_cpus else None   # too few to split: share the node, or leave the scheduler alone
+    return sorted(cpus[k * per:(k + 1) * per])
+
+
+def pin_to_numa(bdfs, local_rank, sysfs_root="/sys"):
+    """Apply numa_cpus_for_rank to this process (all current and future threads inherit it).  Returns the core list or None."""
+    import os
+    if not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = numa_cpus_for_rank(bdfs, local_rank, allowed=sorted(os.sched_getaffinity(0)), sysfs_root=sysfs_root)
+    if cpus:
+        os.sched_setaffinity(0, cpus)
+    return cpus

@@ -52,9 +52,27 @@ def gemv_kernels(tmp_path_factory):
     return kernels
 
 
+KNOWN_COMPILER = "7.2."   # the HIP version whose prologue shape is pinned below (hipcc --version: "HIP version: 7.2.x")
+
+
+def _hip_version():
+    try:
+        out = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout
+        m = re.search(r"HIP version:\s*(\S+)", out)
+        return m.group(1) if m else ""
+    except OSError:
+        return ""
+
+
 def test_kernarg_preload_is_on_for_the_decode_kernels(gemv_kernels):
-    """-amdgpu-kernarg-preload-count (build.py FILE_FLAGS): the kernels start with the backward-compatibility prologue that
-    loads exactly the preloaded arguments -- three s_load + one wait, nothing else -- i.e. 14 leading dwords are preloaded."""
+    """-amdgpu-kernarg-preload-count=16 (build.py FILE_FLAGS; a HIDDEN LLVM option): 16 is the upper bound of SGPRs the
+    dispatcher may fill; the GEMV signatures lead with 14 dwords of hot scalars, and the kernels start with the
+    backward-compatibility prologue that loads exactly those -- s_load x2 + x8 + x4, one wait.  The exact sequence is a
+    property of ONE compiler: on another ROCm the check is skipped and the tolerant test below -- no scalar wait
+    in front of the first weight load -- is what still holds the line; WM_NO_KERNARG_PRELOAD=1 is the documented fallback."""
+    ver = _hip_version()
+    if not ver.startswith(KNOWN_COMPILER):
+        pytest.skip("prologue shape pinned for HIP %sx only (this is %r); the tolerant ISA test still runs" % (KNOWN_COMPILER, ver))
     for name, ins in gemv_kernels.items():
         assert ins[0].startswith("s_load_dwordx2") and ins[1].startswith("s_load_dwordx8") and ins[2].startswith("s_load_dwordx4"), (name, ins[:4])
         assert ins[3].startswith("s_waitcnt lgkmcnt(0)"), (name, ins[:4])

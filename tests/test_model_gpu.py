@@ -1627,6 +1627,35 @@ def test_fused_query_cross_attention_is_bitwise_equal_to_the_two_launches(pkg):
     assert len({r.tobytes() for r in outs[0][3]}) >= 6
     assert np.array_equal(outs[0][-1][0], outs[0][3][2])              # row 2 alone == row 2 in the fused group of 8
     assert outs[0][-2].min() < 40                                     # the stop token / budgets did end rows early
+    # more than ONE 16-row block in the fused shape (blk > 0: the means of a block are written by ITS head-0
+    # workgroups, blocks whose rows are all finished are skipped) -- base width, 8 heads x 24 rows = 192 pairs, early stop on
+    # with budgets that finish the whole SECOND block long before the first
+    dims_b = dict(pkg.binding.MODEL_DIMS["base"], n_audio_layer=2, n_text_layer=3)
+    pcm_b = np.stack([tone_chunk(i) if i % 2 else L.synth_chunk(700 + i) for i in range(24)])
+    bud = [40 if i < 16 else 3 + (i % 5) for i in range(24)]
+    bud[5], bud[9] = 6, 13
+    outs_b = []
+    try:
+        for fuse in (1, 0):
+            lib.wmdbg_set_tuning(b"reset", 0)
+            assert lib.wmdbg_set_tuning(b"xattn_fuse_q", fuse) == 0
+            ctx = pkg.binding.Context(dims_b, debug=True)
+            ctx.init_synthetic(43, matrix_gain=LIVELY_GAIN)
+            _perturb_ln_on_device(ctx, dims_b, seed=10)
+            ctx.finalize()
+            ctx.set_lanes(1)
+            free = ctx.transcribe_greedy(pcm_b, prompt, 40)[0]
+            t_es, l_es = ctx.transcribe_greedy(pcm_b, prompt, 40, eot=-1, budgets=bud)
+            outs_b.append((free, t_es, l_es, ctx.transcribe_greedy(pcm_b[17:18], prompt, 40)[0]))
+            ctx.close()
+    finally:
+        lib.wmdbg_set_tuning(b"reset", 0)
+    for a, b in zip(outs_b[0], outs_b[1]):
+        assert np.array_equal(a, b)
+    free, t_es, l_es, solo = outs_b[0]
+    assert list(l_es) == bud and np.array_equal(solo[0], free[17])
+    for i in range(24):                                               # early stop == decode everything and truncate
+        assert np.array_equal(t_es[i, :bud[i]], free[i, :bud[i]])
 
 
 def test_cross_attention_persistent_and_short_lived_shapes_are_bitwise_equal_under_load(pkg):

@@ -1,8 +1,13 @@
-"""GPU probe: how should ONE wm_transcribe_greedy call of B chunks be cut into decode groups over the lanes?  Sweeps the
-preferred group size (debug knob group_chunks; the product's rule is in model_api.cpp) for call sizes between one
-and three groups' worth: audio-s/s of the whole call (front end + encoder + 224-token decode), min of 2 after a warm-up.
+"""GPU probe: how should ONE wm_transcribe_greedy call of B chunks be cut into decode groups over the lanes?  Audio-s/s of the
+whole call (front end + encoder + 224-token decode), min of 2 after a warm-up, for a list of policies (columns):
 
-    python tools/gpu_group_policy_probe.py [model] [B,B,...] [gc,gc,...]"""
+    gc=N        unmasked lanes, preferred group size N (debug knob group_chunks; N = 128: one group up to 128 chunks)
+    parts=P     P CU-masked sub-chip lanes (round 6: hipExtStreamCreateWithCUMask), a slice of the CUs of every XCD each
+    partsx=P    the same with whole XCDs per lane (lane_mask_kind = 1)
+    product     the product's own rule (no knob)
+
+    python tools/gpu_group_policy_probe.py [model] [B,B,...] [col,col,...]
+Every column's tokens are compared with the first column's ('!' = differ: a launch-shape choice must never change a token)."""
 import ctypes
 import os
 import sys
@@ -19,25 +24,46 @@ B = pkg.binding
 def main():
     model = sys.argv[1] if len(sys.argv) > 1 else "large-v2"
     sizes = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "9,12,15,16,20,24,32,48").split(",")]
-    gcs = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "8,12,16,24,128").split(",")]
+    cols = (sys.argv[3] if len(sys.argv) > 3 else "gc=8,gc=128,parts=2,parts=3,product").split(",")
     lib = B.load_debug_library()
     lib.wmdbg_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
     lib.wmdbg_set_tuning(b"reset", 0)
     dims = B.MODEL_DIMS[model]
-    ctx = B.Context(dims, debug=True)
-    ctx.init_synthetic(20240928, matrix_gain=4.0)
-    ctx.finalize()
     rng = np.random.default_rng(1)
     nmax = max(sizes)
     pcm = np.round(np.clip(0.1 * rng.standard_normal((nmax, 480000)), -1, 1) * 32767).astype(np.int16)
-    dp = ctx.to_device(pcm)
-    prompt = [50258, 50259, 50359, 50363]
-    print("%s: audio-s/s of one call of B chunks by preferred group size (3 lanes); groups shown as n x size" % model)
-    print("B    " + "".join("gc=%-12d" % g for g in gcs))
+    prompt = [50258, 50259, 50359, 50363] if dims["n_vocab"] >= 51865 else [50257, 50362]
+    ctxs = {}
+
+    def ctx_for(kind):   # the CU masks are fixed when a lane's stream is created: one context per mask kind
+        if kind not in ctxs:
+            lib.wmdbg_set_tuning(b"lane_mask_kind", kind)
+            c = B.Context(dims, debug=True)
+            c.init_synthetic(20240928, matrix_gain=4.0)
+            c.finalize()
+            ctxs[kind] = (c, c.to_device(pcm))
+        return ctxs[kind]
+
+    print("%s: audio-s/s of one call of B chunks by group policy (3 lanes available)" % model)
+    print("B    " + "".join("%-13s" % c for c in cols))
     for nb in sizes:
         row, ref = "%-4d " % nb, None
-        for gc in gcs:
-            assert lib.wmdbg_set_tuning(b"group_chunks", gc) == 0
+        for col in cols:
+            lib.wmdbg_set_tuning(b"group_chunks", 0)
+            lib.wmdbg_set_tuning(b"lane_parts", 0)
+            kind = 0
+            if col.startswith("gc="):
+                lib.wmdbg_set_tuning(b"group_chunks", int(col[3:]))
+                lib.wmdbg_set_tuning(b"lane_parts", 1)
+            elif col.startswith("partsx="):
+                kind = 1
+                lib.wmdbg_set_tuning(b"lane_parts", int(col[7:]))
+            elif col.startswith("parts="):
+                lib.wmdbg_set_tuning(b"lane_parts", int(col[6:]))
+            else:
+                assert col == "product", col
+            ctx, dp = ctx_for(kind)
+            lib.wmdbg_set_tuning(b"lane_mask_kind", kind)
             best = None
             for i in range(3):
                 t0 = time.perf_counter()
@@ -45,14 +71,14 @@ def main():
                 dt = time.perf_counter() - t0
                 if i and (best is None or dt < best):
                     best = dt
-            ok = "" if ref is None or np.array_equal(ref, toks) else "!"
+            ok = " " if ref is None or np.array_equal(ref, toks) else "!"
             ref = toks if ref is None else ref
-            g = -(-nb // gc) if nb <= gc * 3 else max(3, -(-nb // 128))
-            row += "%7.0f%s (%dx%d) " % (30.0 * nb / best, ok, g, -(-nb // g))
+            row += "%8.0f%s    " % (30.0 * nb / best, ok)
         print(row, flush=True)
     lib.wmdbg_set_tuning(b"reset", 0)
-    ctx.dev_free(dp)
-    ctx.close()
+    for c, dp in ctxs.values():
+        c.dev_free(dp)
+        c.close()
 
 
 if __name__ == "__main__":
