@@ -67,6 +67,10 @@ WM_API int wmdbg_bench_gemm(wm_ctx *ctx, int M, int N, int K, int epi, int iters
 
 /* Force the encoder GEMM tile: 128 (128 x 128, 4 waves), 256 (256 x 256, 8 waves, staggered phases) or 0 = automatic.
  * Process-wide; used by the parity tests and A/B probes to run every shape through both kernels. */
+/* sub-chip lanes (round 6): CU-masked decode groups of a wm_transcribe_greedy call (0: none, 2: two half-chip groups) for a
+ * call of B chunks on a model of decoder width n_text_state; the 256-bit CU mask of the CUs [cu_lo, cu_hi) of every XCD */
+WM_API int wmdbg_lane_parts(int B, int lanes, int explicit_lanes, int n_text_state);
+WM_API int wmdbg_cu_mask(int cu_lo, int cu_hi, uint32_t *mask8);
 WM_API int wmdbg_set_gemm_tile(int tile);
 
 /* The ALL-FP32 debug model path (BASELINE.md parity gate: "fp32 debug path must match to <= 1e-4 rel-L2"; csrc/f32_path.hip).

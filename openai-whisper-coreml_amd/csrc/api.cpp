@@ -92,20 +92,21 @@ int wm_ctx_make_current(const wm_ctx *ctx) {
 }
 
 // Bit i of a CU mask enables CU i / 8 of XCD i % 8 (the KFD deals the bits round-robin over the 8 XCCs; measured with the
-// census of tools/cu_mask_lab.hip, profiles/r06_cu_mask_lab.txt): 32 CUs per XCD.
-int wm_cu_mask(int part, int parts, int kind, uint32_t mask[8]) {
+// census of tools/cu_mask_lab.hip, profiles/r06_cu_mask_lab.txt: bits 0..7 = one CU in each XCC, bits 0..31 = four): 32 CUs
+// per XCD.  An XCD cannot be switched OFF by the mask: one whose 32 bits are all zero runs on a fallback set (the 0x0f-bytes
+// mask "XCDs 0-3 only" measured 256 CUs), so a lane is a slice [lo, hi) of the CUs of EVERY XCD -- which also keeps the
+// workgroup id % 8 -> XCD placement the L2 warm-up workgroups and the tile maps assume.
+int wm_cu_mask(int cu_lo, int cu_hi, uint32_t mask[8]) {
     for (int w = 0; w < 8; ++w) mask[w] = 0;
     int n = 0;
     for (int i = 0; i < 256; ++i) {
-        const int xcd = i & 7, cu = i >> 3;
-        const int unit = kind == 1 ? xcd : cu, units = kind == 1 ? 8 : 32;
-        // part p owns the units [p * units / parts, (p + 1) * units / parts)
-        if (unit * parts >= part * units && unit * parts < (part + 1) * units) { mask[i >> 5] |= 1u << (i & 31); ++n; }
+        const int cu = i >> 3;
+        if (cu >= cu_lo && cu < cu_hi) { mask[i >> 5] |= 1u << (i & 31); ++n; }
     }
     return n;
 }
 
-static int ctx_new(int device, wm_ctx **out, int part = 0, int parts = 1) {
+static int ctx_new(int device, wm_ctx **out, int cu_lo = 0, int cu_hi = 32) {
     WM_REQUIRE(out != nullptr, WM_ERR_INVALID, "null out pointer");
     *out = nullptr;
     int n = 0;
@@ -119,11 +120,11 @@ static int ctx_new(int device, wm_ctx **out, int part = 0, int parts = 1) {
     wm_ctx *c = new wm_ctx();
     c->device = device;
     hipError_t se;
-    if (parts > 1) {   // a lane confined to its part of the chip
+    if (cu_lo > 0 || cu_hi < 32) {   // a lane confined to the CUs [cu_lo, cu_hi) of every XCD
         uint32_t mask[8];
-        c->n_cus = wm_cu_mask(part, parts, g_wm_tuning.lane_mask_kind, mask);
-        c->cu_part = part;
-        c->cu_parts = parts;
+        c->n_cus = wm_cu_mask(cu_lo, cu_hi, mask);
+        c->cu_lo = cu_lo;
+        c->cu_hi = cu_hi;
         se = hipExtStreamCreateWithCUMask(&c->stream, 8, mask);
     } else {
         se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -168,10 +169,10 @@ extern "C" int wm_clone(wm_ctx *parent, wm_ctx **out) try {
     return st;
 } WM_API_CATCH
 
-int wm_clone_part(wm_ctx *parent, int part, int parts, wm_ctx **out) {
-    WM_REQUIRE(parent && out && parent->model, WM_ERR_INVALID, "clone_part: bad arguments");
-    WM_REQUIRE(parts >= 2 && parts <= 3 && part >= 0 && part < parts, WM_ERR_INVALID, "clone_part: part %d of %d", part, parts);
-    WM_TRY(ctx_new(parent->device, out, part, parts));
+int wm_clone_cus(wm_ctx *parent, int cu_lo, int cu_hi, wm_ctx **out) {
+    WM_REQUIRE(parent && out && parent->model, WM_ERR_INVALID, "clone_cus: bad arguments");
+    WM_REQUIRE(cu_lo >= 0 && cu_lo < cu_hi && cu_hi <= 32, WM_ERR_INVALID, "clone_cus: CUs [%d, %d) of 32 per XCD", cu_lo, cu_hi);
+    WM_TRY(ctx_new(parent->device, out, cu_lo, cu_hi));
     int st = wm_model_clone(*out, parent);
     if (st != WM_OK) {
         wm_destroy(*out);
@@ -188,6 +189,8 @@ extern "C" void wm_destroy(wm_ctx *ctx) {
         for (wm_ctx *lane : v) wm_destroy(lane);
         v.clear();
     }
+    for (auto &kv : ctx->solo_lanes) wm_destroy(kv.second);
+    ctx->solo_lanes.clear();
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     wm_model_destroy(ctx);

@@ -26,7 +26,7 @@ extern "C" int wmdbg_set_tuning(const char *key, int value) {
         {"gemm_tile", &g_wm_tuning.gemm_tile}, {"gemm_gm", &g_wm_tuning.gemm_gm}, {"no_early_stop", &g_wm_tuning.no_early_stop},
         {"xattn_no_deep", &g_wm_tuning.xattn_no_deep}, {"xattn_never_short", &g_wm_tuning.xattn_never_short},         {"logits_tn", &g_wm_tuning.logits_tn}, {"enc_attn_mfma_sum", &g_wm_tuning.enc_attn_mfma_sum},
         {"group_chunks", &g_wm_tuning.group_chunks}, {"argmax_rows_per_wg", &g_wm_tuning.argmax_rows_per_wg}, {"xattn_fuse_q", &g_wm_tuning.xattn_fuse_q}, {"xattn_pair_wg_max_pairs", &g_wm_tuning.xattn_pair_wg_max_pairs},
-        {"lane_parts", &g_wm_tuning.lane_parts}, {"lane_mask_kind", &g_wm_tuning.lane_mask_kind},
+        {"lane_parts", &g_wm_tuning.lane_parts}, {"lane_solo_cus", &g_wm_tuning.lane_solo_cus},
     };
     if (strcmp(key, "reset") == 0) { g_wm_tuning = WmTuning(); return WM_OK; }
     for (auto &e : table)
@@ -36,6 +36,10 @@ extern "C" int wmdbg_set_tuning(const char *key, int value) {
 }
 
 extern "C" int wmdbg_group_count(int B, int lanes, int explicit_lanes) { return wm_group_count(B, lanes, explicit_lanes != 0, 0); }
+extern "C" int wmdbg_lane_parts(int B, int lanes, int explicit_lanes, int n_text_state) {
+    return wm_lane_parts(B, lanes, explicit_lanes != 0, n_text_state, 0);
+}
+extern "C" int wmdbg_cu_mask(int cu_lo, int cu_hi, uint32_t *mask8) { return wm_cu_mask(cu_lo, cu_hi, mask8); }
 
 extern "C" int wmdbg_mel_filterbank(int n_mels, float *out) {
     WM_REQUIRE(out && n_mels > 0 && n_mels <= 256, WM_ERR_INVALID, "bad args");

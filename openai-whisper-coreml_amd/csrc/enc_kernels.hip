@@ -143,8 +143,11 @@ constexpr int ATT_RING = 3;
 
 #define ATT_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 
-template <bool SUM_MFMA>
-__global__ __launch_bounds__(256, 2) void enc_attn_kernel(const bf16_t *__restrict__ qk,
+// (Round 6, measured and dropped: 64-query workgroups of TWO waves for a single chunk -- Whisper-small x 1 chunk = 144
+// workgroups of four waves on 256 CUs -> 288 of two; each wave then issues four DMA pieces per operand and tile, the
+// kernel needs more than 256 VGPRs' worth of live state and runs at one wave per SIMD: encoder 1.457 -> 1.599 ms.)
+template <bool SUM_MFMA, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 2) void enc_attn_kernel(const bf16_t *__restrict__ qk,
                                                           const bf16_t *__restrict__ vt,
                                                           bf16_t *__restrict__ att, int H, int S,
                                                           int S_pad, int d, int n_q, int n_bh) {
@@ -161,7 +164,8 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const bf16_t *__restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hf = lane >> 5;
-    const int q = qblk * 128 + wave * 32 + ql;
+    constexpr int PPW = 8 / NW;   // 1-KiB DMA pieces per operand, tile and wave
+    const int q = qblk * (NW * 32) + wave * 32 + ql;
     const int qc = q < S ? q : S - 1;
     const long ld = 2L * d;
 
@@ -178,20 +182,20 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const bf16_t *__restri
     // (sr & 15) of the super-row: tile row 2 sr + p / 8, 16-byte chunk p % 8.
     const char *kbase = (const char *)(qk + (long)b * S * ld + d + h * 64);
     const char *vbase = (const char *)(vt + (long)(b * H + h) * 64 * S_pad);
-    unsigned ksrc[2], vsrc[2];
+    unsigned ksrc[PPW], vsrc[PPW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int sr = (wave * 2 + i) * 4 + (lane >> 4);
+    for (int i = 0; i < PPW; ++i) {
+        const int sr = (wave * PPW + i) * 4 + (lane >> 4);
         const int pl = (lane & 15) ^ (sr & 15);
         const int row = 2 * sr + (pl >> 3), chunk = pl & 7;
         ksrc[i] = (unsigned)(row * ld * 2 + chunk * 16);
         vsrc[i] = (unsigned)(row * S_pad * 2 + chunk * 16);
     }
     const unsigned kstep = (unsigned)(64 * ld * 2);   // bytes between consecutive 64-key tiles of K (V^T: 128)
-    auto issue = [&](int slot, unsigned kadv, unsigned vadv) {
-        char *dk = ring + slot * ATT_SLOT_BYTES + wave * 2048;   // wave-uniform; the hardware adds lane * 16
+    auto issue = [&](unsigned slot_off, unsigned kadv, unsigned vadv) {   // slot_off: byte offset of the ring slot
+        char *dk = ring + slot_off + wave * (PPW * 1024);   // wave-uniform; the hardware adds lane * 16
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PPW; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kbase + (ksrc[i] + kadv)),
                                              (__attribute__((address_space(3))) void *)(dk + i * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vbase + (vsrc[i] + vadv)),
@@ -223,21 +227,30 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const bf16_t *__restri
     for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
 
     const int ntiles = (S + 63) / 64;
-    issue(0, 0u, 0u);
-    if (ntiles > 1) issue(1, kstep, 128u);
-    // the Q loads and tile 0 have landed once at most the 4 pieces of tile 1 are outstanding (vmcnt counts in order)
-    if (ntiles > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue(0u, 0u, 0u);
+    if (ntiles > 1) issue((unsigned)ATT_SLOT_BYTES, kstep, 128u);
+    // the Q loads and tile 0 have landed once at most the 2 PPW pieces of tile 1 are outstanding (vmcnt counts in order)
+    if (ntiles > 1) {
+        if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     // One 64-key tile.  FIRST: the reference is taken from this tile's maximum (unconditionally: l >= 1 from then on);
     // LAST: keys >= S masked (the only tile that can hold any).
+    // (round 6) The ring-slot byte offset of the current tile (so) and of the slot the DMA fills (io) are carried as
+    // wave-uniform counters that cycle 0 -> 16 K -> 32 K -> 0 (one add + compare + select on the scalar unit each) instead
+    // of two `% 3` sequences per tile, and the fragment addresses are fa[] + so: 4 VALU adds instead of 12 in a loop that
+    // is bound by VALU issue (profiles/r06_pmc_encoder_stalls.txt: 8.5 VALU instructions per MFMA).
+    unsigned so = 0u, io = 2u * ATT_SLOT_BYTES;
     auto tile = [&](int j, auto first_tag, auto last_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr bool LAST = decltype(last_tag)::value;
-        const int slot = j % ATT_RING;
-        if (j + 2 < ntiles) issue((j + 2) % ATT_RING, (unsigned)(j + 2) * kstep, (unsigned)(j + 2) * 128u);
-        const unsigned so = (unsigned)(slot * ATT_SLOT_BYTES);
+        if (j + 2 < ntiles) issue(io, (unsigned)(j + 2) * kstep, (unsigned)(j + 2) * 128u);
         const unsigned a0 = fa[0] + so, a1 = fa[1] + so, a2 = fa[2] + so, a3 = fa[3] + so;
+        so = so == 2u * ATT_SLOT_BYTES ? 0u : so + ATT_SLOT_BYTES;
+        io = io == 2u * ATT_SLOT_BYTES ? 0u : io + ATT_SLOT_BYTES;
         // ---- S^T - r = K Q^T + (-r) : two 32-kv blocks, the reference enters as the C operand -----------
         bf16x8 kf[2][4];
         ATT_DSR(kf[0][0], a0, 0); ATT_DSR(kf[0][1], a1, 0); ATT_DSR(kf[0][2], a2, 0); ATT_DSR(kf[0][3], a3, 0);
@@ -293,6 +306,9 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const bf16_t *__restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) cneg[r] = -ref;
         }
+        // ONE register tuple for the reference across the rare branch: without this the compiler keeps a second copy and
+        // refreshes it with 8 v_mov_b64 on EVERY tile (round 6, read off the ISA)
+        asm volatile("" : "+v"(cneg));
         // ---- P^T = exp2(S^T - r) -> bf16;  O^T += V^T P^T;  l += 1^T P^T -------------------------------
         bf16x8 pf[2][2];
 #pragma unroll
@@ -320,8 +336,12 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const bf16_t *__restri
         // the NEXT tile must have landed (this wave's share: everything but the 4 pieces just issued), and every wave must
         // be done reading this slot before the tile after next overwrites it
         if (!LAST) {
-            if (j + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (j + 2 < ntiles) {
+                if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
         }
     };

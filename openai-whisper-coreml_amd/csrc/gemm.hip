@@ -21,6 +21,8 @@
 //     of an output frame is a CONTIGUOUS run of 3*C elements.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "model.h"
 
 // No implicit FMA contraction in this file: the two tile shapes (and their different epilogue code paths) must round
@@ -413,6 +415,120 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmDev p) {
 }
 
 // =================================================================================================
+// 64 x 64 x 64 tile for products that cannot fill the chip with 128 x 128 tiles (round 6): ONE 30 s chunk (M = 1500) -- the
+// reference's own flow (Whisper.swift:23-31, one chunk of Whisper-small) -- has 72 tiles of 128 x 128 for its N = 768 products
+// (out-projection, fc2 with K = 3072, conv2) on 256 CUs; as 64 x 64 tiles they are 288 workgroups.  Same structure as the
+// 128 tile (4 waves as 2 x 2, LDS-DMA double buffer, XOR swizzle), each wave owns 32 x 32 = 2 x 2 fragments; 2 x 16 KiB of LDS,
+// so several workgroups share a CU.  Every output element is accumulated over K in the same order by the same MFMA and
+// finished by the same epilogue arithmetic: bitwise equal to the other tiles (test).
+constexpr int BM3 = 64, BN3 = 64;
+constexpr int TILE3_BYTES = BM3 * BK * 2;   // 8 KiB per operand tile
+constexpr int STAGE3_BYTES = 2 * TILE3_BYTES;  // A + W of one K-tile
+constexpr int NST3 = 4;                      // K-tiles in flight (ring of 4 x 16 KiB)
+
+#define WM_DSR3(dst, addr, off) \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
+
+// A single-chunk product is LATENCY-bound per K-tile (4 MFMAs per wave against one HBM / L2 round trip), and with ~1
+// workgroup per CU nothing else hides it: K-tiles are streamed THREE ahead of the one being multiplied (LDS-DMA into a
+// 4-slot ring, counted s_waitcnt vmcnt(8), one barrier per K-tile; the loads past the end of K re-request the last tile so
+// the count stays constant).  ds_reads in inline asm, as in the 256 kernel: hipcc would otherwise drain vmcnt(0) in front
+// of every LDS read that may alias an outstanding LDS-DMA.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm64_bf16_kernel(GemmDev p) {
+    __shared__ __attribute__((aligned(1024))) char lds[NST3 * STAGE3_BYTES];
+    int tm, tn;
+    tile_of_workgroup(p, tm, tn);
+    const int m0 = tm * BM3, n0 = tn * BN3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    // staging: 2 passes x (32 rows x 8 chunks of 16 B) per operand; thread -> (row = pass*32 + tid/8, physical chunk tid%8)
+    const int srow = tid >> 3, pch = tid & 7;
+    const bf16_t *a_src[2];
+    const bf16_t *w_src[2];
+    const unsigned arpb = p.a_rpb > 0x7fffffffL ? 0x7fffffffu : (unsigned)p.a_rpb;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = i * 32 + srow;
+        const int lch = pch ^ (row & 7);
+        unsigned m = (unsigned)(m0 + row);
+        if (m > (unsigned)(p.M - 1)) m = (unsigned)(p.M - 1);  // clamp: tail rows are masked in the epilogue
+        const unsigned aq = m / arpb, ar = m - aq * arpb;
+        a_src[i] = p.A + (long)aq * p.a_bstride + (long)ar * p.a_rstride + lch * 8;
+        long n = n0 + row;
+        if (n > p.N - 1) n = p.N - 1;
+        w_src[i] = p.W + n * (long)p.K + lch * 8;
+    }
+    const int nk = p.K / BK;
+    auto stage = [&](int slot, int kt) {   // 4 LDS-DMA instructions per wave
+        const long ko = (long)(kt < nk ? kt : nk - 1) * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            char *da = lds + slot * STAGE3_BYTES + (i * 32 + wave * 8) * 128;   // wave-uniform base; the hardware adds lane * 16
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a_src[i] + ko),
+                                             (__attribute__((address_space(3))) void *)da, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_src[i] + ko),
+                                             (__attribute__((address_space(3))) void *)(da + TILE3_BYTES), 16, 0, 0);
+        }
+    };
+    // fragment read addresses (slot 0; the slot and the operand are immediates): row r, k-step ks -> r * 128 + ((ks*4+fq) ^ (r & 7)) * 16
+    const int frow = lane & 15, fq = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+    unsigned aa[2][2], wa[2][2];   // [fragment][k-step]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ra = wr * 32 + i * 16 + frow, rb = wc * 32 + i * 16 + frow;
+            aa[i][ks] = lds0 + (unsigned)(ra * 128 + (((ks * 4 + fq) ^ (ra & 7)) << 4));
+            wa[i][ks] = lds0 + (unsigned)(rb * 128 + (((ks * 4 + fq) ^ (rb & 7)) << 4));
+        }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    stage(0, 0);
+    stage(1, 1);
+    stage(2, 2);
+    auto step = [&](int kt, auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        constexpr int SO = SLOT * STAGE3_BYTES;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's pieces of K-tile kt have landed (kt + 1, kt + 2 may be in flight)
+        __builtin_amdgcn_s_barrier();                        // ... everybody's; and everybody is done reading K-tile kt - 1
+        stage((SLOT + 3) % NST3, kt + 3);                    // into the slot K-tile kt - 1 lived in
+        bf16x8 af[2][2], bfr[2][2];
+        WM_DSR3(af[0][0], aa[0][0], SO); WM_DSR3(af[1][0], aa[1][0], SO);
+        WM_DSR3(bfr[0][0], wa[0][0], SO + TILE3_BYTES); WM_DSR3(bfr[1][0], wa[1][0], SO + TILE3_BYTES);
+        WM_DSR3(af[0][1], aa[0][1], SO); WM_DSR3(af[1][1], aa[1][1], SO);
+        WM_DSR3(bfr[0][1], wa[0][1], SO + TILE3_BYTES); WM_DSR3(bfr[1][1], wa[1][1], SO + TILE3_BYTES);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(af[0][0]), "+v"(af[1][0]), "+v"(bfr[0][0]), "+v"(bfr[1][0]), "+v"(af[0][1]), "+v"(af[1][1]),
+                       "+v"(bfr[0][1]), "+v"(bfr[1][1])::"memory");
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)   // (k ascending within the tile: the order every tile shape accumulates in)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][ks], bfr[j][ks], acc[i][j], 0, 0, 0);
+    };
+    int kt = 0;
+    for (; kt + 4 <= nk; kt += 4) {
+        step(kt, std::integral_constant<int, 0>{});
+        step(kt + 1, std::integral_constant<int, 1>{});
+        step(kt + 2, std::integral_constant<int, 2>{});
+        step(kt + 3, std::integral_constant<int, 3>{});
+    }
+    if (kt < nk) { step(kt, std::integral_constant<int, 0>{}); ++kt; }   // (workgroup-uniform remainders)
+    if (kt < nk) { step(kt, std::integral_constant<int, 1>{}); ++kt; }
+    if (kt < nk) { step(kt, std::integral_constant<int, 2>{}); ++kt; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-requested tail tiles: nothing may land in LDS after the kernel's end
+    store_tile<EPI, 2, 2>(p, acc, m0 + wr * 32 + fq * 4, n0 + wc * 32 + frow);
+}
+
+// =================================================================================================
 // 256 x 256 x 64 tile for the large encoder products: 512 threads = 8 wave64 as 2(M) x 4(N), each wave
 // owns 128 x 64 of C (8 x 4 fragments, 128 accumulator registers); one workgroup per CU (128 KiB LDS).
 //
@@ -612,15 +728,16 @@ __global__ __attribute__((amdgpu_flat_work_group_size(512, 512), amdgpu_waves_pe
 
 // A/B and parity probes force one of the two tile shapes (the wmdbg_set_gemm_tile hook lives in debug_hooks.cpp)
 int wm_gemm_set_tile_override(int tile) {
-    if (tile != 0 && tile != 128 && tile != 256) return WM_ERR_INVALID;
+    if (tile != 0 && tile != 64 && tile != 128 && tile != 256) return WM_ERR_INVALID;
     g_wm_tuning.gemm_tile = tile;
     return WM_OK;
 }
 
 template <int EPI>
-static void launch_gemm(const GemmDev &p, bool big, int grid, hipStream_t s) {
-    if (big) gemm256_bf16_kernel<EPI><<<grid, 512, 0, s>>>(p);
-    else gemm_bf16_kernel<EPI><<<grid, 256, 0, s>>>(p);
+static void launch_gemm(const GemmDev &p, int tile, int grid, hipStream_t s) {
+    if (tile == 256) gemm256_bf16_kernel<EPI><<<grid, 512, 0, s>>>(p);
+    else if (tile == 128) gemm_bf16_kernel<EPI><<<grid, 256, 0, s>>>(p);
+    else gemm64_bf16_kernel<EPI><<<grid, 256, 0, s>>>(p);
 }
 
 int wm_gemm(wm_ctx *ctx, const GemmArgs &g) {
@@ -632,14 +749,17 @@ int wm_gemm(wm_ctx *ctx, const GemmArgs &g) {
     p.c_rpb = g.c_rpb; p.c_bstride = g.c_bstride; p.c_rstride = g.c_rstride;
     p.M = g.M; p.N = g.N; p.K = g.K; p.pos = g.pos; p.vt = g.vt;
     p.d_model = g.d_model; p.n_head = g.n_head; p.seq = g.seq; p.seq_pad = g.seq_pad; p.batch = g.batch;
-    // Tile choice: the 256 x 256 staggered-phase kernel once it can put a workgroup on most CUs (one per CU);
-    // the 128 x 128 kernel (two per CU) for everything smaller.  (g_wm_tuning.gemm_tile: the debug library's tests / probes.)
+    // Tile choice: the 256 x 256 staggered-phase kernel once it can put a workgroup on most CUs (one per CU); the 128 x 128
+    // kernel (two per CU) below that; the 64 x 64 kernel when even 128 x 128 tiles leave most of the chip idle (fewer than 160
+    // tiles: one 30 s chunk at N = d -- small: 72 -> 288 workgroups; the 128 tile keeps products whose 128-grid fills the chip).
+    // (g_wm_tuning.gemm_tile: the debug library's tests / probes.)
     const int env_tile = g_wm_tuning.gemm_tile;
     const long tiles256 = (long)((g.M + BM2 - 1) / BM2) * ((g.N + BN2 - 1) / BN2);
-    bool big = g.K >= 2 * BK && tiles256 >= 160;
-    if (env_tile == 128) big = false;
-    if (env_tile == 256) big = g.K >= 2 * BK;
-    const int bm = big ? BM2 : BM, bn = big ? BN2 : BN;
+    const long tiles128 = (long)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    int tile = (g.K >= 2 * BK && tiles256 >= 160) ? 256 : (tiles128 >= 160 ? 128 : 64);
+    if (env_tile == 64 || env_tile == 128) tile = env_tile;
+    if (env_tile == 256 && g.K >= 2 * BK) tile = 256;
+    const int bm = tile == 256 ? BM2 : tile == 128 ? BM : BM3, bn = tile == 256 ? BN2 : tile == 128 ? BN : BN3;
     p.tiles_m = (g.M + bm - 1) / bm;
     p.tiles_n = (g.N + bn - 1) / bn;
     const int grid = p.tiles_m * p.tiles_n;
@@ -649,13 +769,13 @@ int wm_gemm(wm_ctx *ctx, const GemmArgs &g) {
     WmProfScope ps(&ctx->prof, names[g.epi], ctx->stream);
     hipStream_t st = ctx->stream;
     switch (g.epi) {
-        case EPI_BIAS_BF16: launch_gemm<EPI_BIAS_BF16>(p, big, grid, st); break;
-        case EPI_GELU_BF16: launch_gemm<EPI_GELU_BF16>(p, big, grid, st); break;
-        case EPI_RESID_F32: launch_gemm<EPI_RESID_F32>(p, big, grid, st); break;
-        case EPI_CONV2_F32: launch_gemm<EPI_CONV2_F32>(p, big, grid, st); break;
-        case EPI_QKV_ENC: launch_gemm<EPI_QKV_ENC>(p, big, grid, st); break;
-        case EPI_XKV: launch_gemm<EPI_XKV>(p, big, grid, st); break;
-        case EPI_F32: launch_gemm<EPI_F32>(p, big, grid, st); break;
+        case EPI_BIAS_BF16: launch_gemm<EPI_BIAS_BF16>(p, tile, grid, st); break;
+        case EPI_GELU_BF16: launch_gemm<EPI_GELU_BF16>(p, tile, grid, st); break;
+        case EPI_RESID_F32: launch_gemm<EPI_RESID_F32>(p, tile, grid, st); break;
+        case EPI_CONV2_F32: launch_gemm<EPI_CONV2_F32>(p, tile, grid, st); break;
+        case EPI_QKV_ENC: launch_gemm<EPI_QKV_ENC>(p, tile, grid, st); break;
+        case EPI_XKV: launch_gemm<EPI_XKV>(p, tile, grid, st); break;
+        case EPI_F32: launch_gemm<EPI_F32>(p, tile, grid, st); break;
         default: wm_set_error("gemm: bad epilogue %d", g.epi); return WM_ERR_INVALID;
     }
     WM_HIP(hipGetLastError());

@@ -64,6 +64,7 @@ extern "C" int wm_set_suppress(wm_ctx *ctx, const int32_t *suppress, int n, cons
     for (wm_ctx *lane : ctx->lanes) WM_TRY(wm_model_set_suppress(lane, suppress, n, suppress_first, n_first));
     for (auto &v : ctx->part_lanes)
         for (wm_ctx *lane : v) WM_TRY(wm_model_set_suppress(lane, suppress, n, suppress_first, n_first));
+    for (auto &kv : ctx->solo_lanes) WM_TRY(wm_model_set_suppress(kv.second, suppress, n, suppress_first, n_first));
     return WM_OK;
 } WM_API_CATCH
 extern "C" int wm_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t timestamp_begin, int32_t eot,
@@ -76,6 +77,8 @@ extern "C" int wm_set_timestamp_rules(wm_ctx *ctx, int enable, int32_t timestamp
     for (auto &v : ctx->part_lanes)
         for (wm_ctx *lane : v)
             WM_TRY(wm_model_set_timestamp_rules(lane, enable, timestamp_begin, eot, max_initial_timestamp_index));
+    for (auto &kv : ctx->solo_lanes)
+        WM_TRY(wm_model_set_timestamp_rules(kv.second, enable, timestamp_begin, eot, max_initial_timestamp_index));
     return WM_OK;
 } WM_API_CATCH
 extern "C" int wm_set_lanes(wm_ctx *ctx, int n_lanes) try {
@@ -558,17 +561,26 @@ int wm_group_count(int B, int L, bool explicit_lanes, int gc_probe) {
     return G < g_min ? g_min : (G < 1 ? 1 : G);
 }
 
-// SUB-CHIP LANES (round 6): P = 2 or 3 decode groups of a call, each on its OWN part of the chip -- weight-sharing clones whose
-// streams carry complementary CU masks (wm_clone_part) -- instead of one latency-bound chain (HBM ~70 % idle between 9 and 64
-// chunks at large-v2) or unmasked chains whose every launch floods all 256 CUs.  Returns 0 when the call is served better by
-// the unmasked lanes of wm_group_count.  Measured: profiles/r06_group_policy.txt.  Launch shapes only: same kernels, same bits.
+// SUB-CHIP LANES (round 6): P = 2 (or 3) decode groups of a call, each on its OWN part of the chip -- weight-sharing clones
+// whose streams carry complementary CU masks (wm_clone_cus: a slice of the CUs of every XCD) -- instead of one
+// latency-bound chain, or unmasked chains whose every launch floods all 256 CUs.  Returns 0 when the call is served better
+// by the unmasked lanes of wm_group_count.  Launch shapes only: same kernels, same bits (tests).
+// MEASURED (profiles/r06_group_policy.txt, r06_solo_lane_latency.txt): whether it pays is decided by how much ONE chain
+// needs the CUs.  A NARROW model's chain does not (base, 16 rows: 0.2375 ms per position on 256 CUs, 0.2452 on 128 --
+// launch latency, the matrices are 0.5-2 MB), so two half-chip chains run truly side by side: base x 32 +7 % over the best
+// unmasked split (14 350 vs 13 400 audio-s/s), x 64 +9 %, tiny.en x 32 +6 %.  A WIDE model's chain does: large-v2, 8 rows,
+// 1.55 ms per position on 256 CUs, 2.21 on 128 -- the streaming phases of its big launches are bound by bytes in flight PER
+// CU (cross-attention 61 MB: 16.4 -> 27.1 us, fc1 13 MB: 6.4 -> 10.7 us on half the CUs), so two half-chip chains lose to
+// one group at every size (15 chunks: 765 vs 937; 24: 1098 vs 1170; 48: 1522 vs 1582) and three thirds lose more.
 int wm_lane_parts(int B, int L, bool explicit_lanes, int n_text_state, int n_text_layer) {
-    (void)n_text_state; (void)n_text_layer;
+    (void)n_text_layer;
     const int knob = g_wm_tuning.lane_parts;     // 0 in the product
     if (knob == 1) return 0;
     if (knob == 2 || knob == 3) return (B >= 2 * knob && B <= knob * WM_DEC_MAXB) ? knob : 0;
     if (explicit_lanes || L < 2) return 0;       // a host that sets a lane count gets the lanes it asked for
-    return 0;
+    if (n_text_state <= 384) return (B >= 32 && B < 48) ? 2 : 0;      // tiny: 32 .. 47 chunks (+6 %; -2 % from 48)
+    if (n_text_state <= 512) return (B >= 24 && B <= 128) ? 2 : 0;    // base: 24 .. 128 chunks (+2 .. +9 %; 40 - 48: -1 %)
+    return 0;                                    // d >= 768: the chain needs the whole chip
 }
 
 extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype, int B,
@@ -611,14 +623,22 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
     // 8 chunks for each -- the rounds-1-4 rule, and what keeps the lanes under test at small sizes.
     const bool explicit_lanes = ctx->max_lanes > 0;
     const int L = ctx->prof.on ? 1 : (explicit_lanes ? ctx->max_lanes : lane_limit());
-    const int parts = ctx->prof.on ? 0 : wm_lane_parts(B, L, explicit_lanes, D.n_text_state, D.n_text_layer);
+    const int solo = g_wm_tuning.lane_solo_cus;   // probes only (0 in the product)
+    const int parts = (ctx->prof.on || solo) ? 0 : wm_lane_parts(B, L, explicit_lanes, D.n_text_state, D.n_text_layer);
     const int G = parts ? parts : wm_group_count(B, L, explicit_lanes, g_wm_tuning.group_chunks);
-    const int n_lanes = parts ? parts : (G < L ? G : L);
-    if (parts) {
+    const int n_lanes = solo ? 1 : (parts ? parts : (G < L ? G : L));
+    wm_ctx *solo_ctx = nullptr;
+    if (solo) {
+        WM_REQUIRE(solo >= 1 && solo <= 31, WM_ERR_INVALID, "lane_solo_cus: 1 .. 31 CUs per XCD");
+        wm_ctx *&c = ctx->solo_lanes[solo];
+        if (!c) WM_TRY(wm_clone_cus(ctx, 0, solo, &c));
+        solo_ctx = c;
+    } else if (parts) {
         std::vector<wm_ctx *> &pl = ctx->part_lanes[parts - 2];
         while ((int)pl.size() < parts) {
             wm_ctx *c = nullptr;
-            WM_TRY(wm_clone_part(ctx, (int)pl.size(), parts, &c));
+            const int k = (int)pl.size();
+            WM_TRY(wm_clone_cus(ctx, k * 32 / parts, (k + 1) * 32 / parts, &c));   // 16 + 16, or 10 + 11 + 11 CUs of every XCD
             pl.push_back(c);
         }
     } else {
@@ -630,7 +650,7 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
     }
     std::vector<LaneJob> jobs(n_lanes);
     for (int l = 0; l < n_lanes; ++l) {
-        jobs[l].c = parts ? ctx->part_lanes[parts - 2][l] : (l == 0 ? ctx : ctx->lanes[l - 1]);
+        jobs[l].c = solo_ctx ? solo_ctx : parts ? ctx->part_lanes[parts - 2][l] : (l == 0 ? ctx : ctx->lanes[l - 1]);
         for (auto &e : jobs[l].ev) WM_HIP(hipEventCreate(&e));
         if (stop.on)
             for (auto &e : jobs[l].burst_ev) WM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -147,16 +147,17 @@ struct wm_ctx {
     const WmDebugHooks *dbg_hooks = nullptr;
     int max_lanes = 0;            // wm_set_lanes: decode groups in flight per wm_transcribe_greedy call (0: $WM_LANES, default 3)
     // SUB-CHIP LANES (round 6).  A context whose stream was created with a CU mask (hipExtStreamCreateWithCUMask) runs
-    // everything it launches on `n_cus` of the 256 CUs: part `cu_part` of a `cu_parts`-way partition of the chip.  Two or
+    // everything it launches on `n_cus` of the 256 CUs: the CUs [cu_lo, cu_hi) of every XCD.  Two or
     // three SMALL decode groups (latency-bound launch chains) then run side by side on disjoint CUs instead of flooding
     // all 256 CUs with every launch and serialising at the CU level (model_api.cpp, the group policy).
-    int n_cus = 256, cu_part = 0, cu_parts = 1;
+    int n_cus = 256, cu_lo = 0, cu_hi = 32;   // the CUs [cu_lo, cu_hi) of every XCD
     std::vector<wm_ctx *> part_lanes[2];   // [0]: the two clones of the 2-way partition, [1]: the three of the 3-way one (created on first use)
+    std::map<int, wm_ctx *> solo_lanes;    // probes (debug knob lane_solo_cus): a clone confined to the first n CUs of every XCD
 };
-// weight-sharing clone of `parent` whose stream is confined to part `part` of a `parts`-way CU partition (api.cpp)
-int wm_clone_part(wm_ctx *parent, int part, int parts, wm_ctx **out);
-// CU mask (256 bits) of part `part` of `parts`; kind 0: a slice of the CUs of EVERY XCD, kind 1: whole XCDs.  Returns the CU count.
-int wm_cu_mask(int part, int parts, int kind, uint32_t mask[8]);
+// weight-sharing clone of `parent` whose stream is confined to the CUs [cu_lo, cu_hi) of every XCD (api.cpp)
+int wm_clone_cus(wm_ctx *parent, int cu_lo, int cu_hi, wm_ctx **out);
+// CU mask (256 bits) of the CUs [cu_lo, cu_hi) of every XCD; returns the CU count
+int wm_cu_mask(int cu_lo, int cu_hi, uint32_t mask[8]);
 
 int wm_ctx_make_current(const wm_ctx *ctx);
 int wm_group_count(int B, int L, bool explicit_lanes, int gc_probe);   // model_api.cpp: decode groups of a wm_transcribe_greedy call
@@ -192,7 +193,7 @@ struct WmTuning {
     int argmax_rows_per_wg = 0;   // PROBE: rows per workgroup of the step-closing arg-max (0 = the product's rule: 1, or 16 for <= 16 rows with early stop)
     int group_chunks = 0;         // preferred decode-group size of a wm_transcribe_greedy call (product rule: model_api.cpp)
     int lane_parts = 0;           // sub-chip lanes: 0 = the product's rule, 1 = never, 2 / 3 = that many CU-masked groups whenever the call has >= 2 chunks per part
-    int lane_mask_kind = 0;       // CU partition of the masked lanes: 0 = a slice of the CUs of every XCD, 1 = whole XCDs
+    int lane_solo_cus = 0;        // PROBE: n in 1 .. 31 = run the call's decode groups one after the other on ONE lane confined to the first n CUs of every XCD
 };
 extern WmTuning g_wm_tuning;   // api.cpp
 

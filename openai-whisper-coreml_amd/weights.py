@@ -138,6 +138,23 @@ def synthetic_state_dict(dims, seed=0, matrix_gain=1.0):
     return sd
 
 
+# The "lively" random-init recipe (SYNTHETIC WEIGHTS: NOT FOR PRODUCTION USE -- benchmarks and token-level tests only): with
+# plain N(0, 0.02^2) matrices every chunk and position decodes to the same token, so token cross-checks are blind.  Scaling
+# the matrices makes the token streams depend on the audio and on the decode history -- but the gain that does it depends
+# on the model WIDTH (a d-wide product of 0.02-sigma weights amplifies by 0.02 g sqrt(d)): gain 4, calibrated at d = 1280,
+# left base with 3-4 distinct token rows out of 32 distinct recordings.  Calibrated on an MI355X with
+# tools/gpu_lively_gain_probe.py (profiles/r06_lively_gain.txt): the smallest tried gain at which 32 distinct recordings --
+# seeded noise, and tones + noise -- decode to (all but at most one of) 32 distinct rows.  (A larger gain is a harsher numerical
+# test, not a livelier model: bf16 operand rounding grows with it -- tiny.en's 4-layer encoder is 5.3e-3 rel-L2 from the fp32
+# oracle at gain 8 -- so the smallest adequate gain is the one recorded.)
+LIVELY_GAIN_BY_WIDTH = {384: 6.0, 512: 12.0, 768: 6.0, 1024: 4.0, 1280: 4.0}
+
+
+def lively_gain(dims):
+    """Matrix gain of the lively random-init model of this geometry (by decoder width; 4 for widths not calibrated)."""
+    return LIVELY_GAIN_BY_WIDTH.get(int(dims["n_text_state"]), 4.0)
+
+
 # ------------------------------------------------------------------ flat weight file ----
 def save_flat(path, dims, sd):
     specs = tensor_specs(dims)

@@ -154,3 +154,25 @@ def test_group_policy_of_a_call(pkg):
             for ex in (0, 1):
                 G = g(B, lanes, ex)
                 assert G >= 1 and -(-B // G) <= 128, (B, lanes, ex, G)
+
+
+def test_sub_chip_lane_policy_and_cu_masks(pkg):
+    """Round 6 (model_api.cpp wm_lane_parts, measured: profiles/r06_group_policy.txt): two CU-masked half-chip decode groups
+    for the NARROW models only (their chains do not need the CUs) -- tiny (d 384) at 32 .. 47 chunks, base (d 512) at
+    24 .. 128 -- never for d >= 768 (large-v2 on half the CUs: 1.55 -> 2.21 ms per position), never when the host set a
+    lane count or has one lane.  The masks: a slice of the CUs of EVERY XCD (bit i = CU i / 8 of XCD i % 8), complementary."""
+    import ctypes
+    lib = pkg.binding.load_debug_library()
+    p = lambda B, d, lanes=3, ex=0: lib.wmdbg_lane_parts(B, lanes, ex, d)
+    assert [p(B, 512) for B in (8, 23, 24, 32, 64, 128, 129, 200)] == [0, 0, 2, 2, 2, 2, 0, 0]
+    assert [p(B, 384) for B in (16, 31, 32, 47, 48, 64)] == [0, 0, 2, 2, 0, 0]
+    assert all(p(B, d) == 0 for d in (768, 1024, 1280) for B in (8, 15, 24, 32, 48, 64, 128))
+    assert p(32, 512, lanes=1) == 0 and p(32, 512, ex=1) == 0
+    lib.wmdbg_cu_mask.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]
+    lo, hi = (ctypes.c_uint32 * 8)(), (ctypes.c_uint32 * 8)()
+    assert lib.wmdbg_cu_mask(0, 16, lo) == 128 and lib.wmdbg_cu_mask(16, 32, hi) == 128
+    assert list(lo) == [0xffffffff] * 4 + [0] * 4 and list(hi) == [0] * 4 + [0xffffffff] * 4
+    third = (ctypes.c_uint32 * 8)()
+    assert lib.wmdbg_cu_mask(10, 21, third) == 88                     # 11 CUs of each of the 8 XCDs
+    bits = [i for i in range(256) if third[i // 32] >> (i % 32) & 1]
+    assert bits == list(range(80, 168)) and all(sum(1 for b in bits if b % 8 == x) == 11 for x in range(8))

@@ -159,3 +159,38 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     assert one["n_gpus"] == 1 and one["rccl_ranks"] is None and one["dist_backend"] is None
     # weak scaling over the same device: two ranks time-share one GPU, so the pair cannot be faster than ~1x one rank
     assert two["value"] > 0.4 * one["value"]
+
+
+def test_config5_job_on_one_rank_and_on_two_gloo_ranks():
+    """BASELINE.json configs[4] -- large-v3, one hour of audio = 120 chunks of 30 s, chunk-parallel -- as the JOB the driver
+    would launch with `--gpus 8`, where a one-GPU box can run it (VERDICT r5 next #5c):
+    (a) the whole job on ONE rank: `bench.py --model large-v3 --total-chunks 120 --gpus 1 --steps 1` -- 120 different
+        recordings, 120 pairwise distinct token rows, every token cross-check true, scaling "strong";
+    (b) two REAL ranks sharing device 0 over gloo at --total-chunks 30: 15 chunks per rank = exactly the per-GPU shard of the
+        8-GPU job, block partition + the fixed-stride all-gather, `cpu_baseline` present on a line with n_gpus > 1, the
+        compact `summary` last."""
+    common = ["--model", "large-v3", "--steps", "1", "--warmup", "1", "--no-early-stop", "--no-other-configs"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--total-chunks", "120", "--no-cpu-baseline"]
+                       + common, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    one = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert one["scaling"] == "strong" and one["config"]["total_chunks"] == 120 and one["config"]["chunks_per_gpu"] == 120
+    assert one["token_rows"] == 120 and one["distinct_token_rows"] == 120, (one["token_rows"], one["distinct_token_rows"])
+    assert one["tokens_consistent_across_groups"] is True and len(one["token_checks"]) == 3, one["token_checks"]
+    assert abs(one["value"] - 30.0 * 120 / (one["ms_per_step"] * 1e-3)) < 1e-6 * one["value"]
+    assert list(one)[-1] == "summary" and one["summary"]["value"] == round(one["value"], 1)
+    env2 = dict(env, WM_BENCH_DIST_BACKEND="gloo", WM_BENCH_NO_INSITU="1", HIP_VISIBLE_DEVICES="0", WM_BENCH_LOCAL_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--total-chunks", "30"] + common,
+                       capture_output=True, text=True, timeout=1500, env=env2, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["chunks_per_gpu"] == 15
+    assert two["config"]["parallelism"] == "chunk-dp2" and two["collective_ranks"] == 2 and two["rccl_ranks"] == 0
+    assert two["tokens_consistent_across_groups"] is True and two["token_rows"] == 15 and two["distinct_token_rows"] == 15
+    assert abs(two["value"] - 30.0 * 30 / (two["ms_per_step"] * 1e-3)) < 1e-6 * two["value"]
+    cb = two["cpu_baseline"]                         # the CPU leg now also runs at N > 1 (rank 0, after the timed region)
+    assert cb is not None and cb["kind"] == "port" and (cb["value"] is None or cb["value"] > 0), cb
+    assert list(two)[-1] == "summary" and two["summary"]["n_gpus"] == 2

@@ -42,9 +42,10 @@ def rel(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
 
 
-@pytest.fixture(params=[128, 256])
+@pytest.fixture(params=[64, 128, 256])
 def gemm_tile(ctx, request):
-    """Run a GEMM test through both encoder GEMM kernels (128 x 128 and the 256 x 256 staggered-phase one)."""
+    """Run a GEMM test through the three encoder GEMM kernels (64 x 64 for single-chunk products, 128 x 128 and the
+    256 x 256 staggered-phase one)."""
     ctx.lib.wmdbg_set_gemm_tile.argtypes = [ctypes.c_int]
     assert ctx.lib.wmdbg_set_gemm_tile(request.param) == 0
     yield request.param
@@ -67,7 +68,7 @@ def test_gemm_f32_out(ctx, gemm_tile, M, N, K):
 
 def test_gemm_identity_asymmetric(ctx, gemm_tile):
     """A = I picks rows of W^T: any row<->col swap in the C write shows up exactly."""
-    M = N = K = 128 if gemm_tile == 128 else 512
+    M = N = K = 128 if gemm_tile <= 128 else 512
     A = np.eye(M, K, dtype=np.float32)
     Wt = bf(np.arange(N * K, dtype=np.float32).reshape(N, K) % 251 - 100.0)
     C = np.zeros((M, N), np.float32)
@@ -244,7 +245,8 @@ def test_decode_attention_rejects_bad_split(ctx):
 
 def test_gemm_256_tile_is_bitwise_equal_to_the_128_tile(ctx):
     """Race screen for the staggered-phase 256 x 256 kernel (counted vmcnt, asm ds_reads): it accumulates in the same
-    order as the 128 x 128 kernel, so any difference on the same operands is a synchronisation bug, not rounding.
+    order as the 128 x 128 kernel (and the 64 x 64 one of round 6), so any difference on the same operands is a
+    synchronisation bug, not rounding.
     (tools/gpu_gemm_race_screen.py is the long version: 1080 comparisons next to a running bench, 0 mismatches.)"""
     ctx.lib.wmdbg_set_gemm_tile.argtypes = [ctypes.c_int]
     try:
@@ -256,11 +258,11 @@ def test_gemm_256_tile_is_bitwise_equal_to_the_128_tile(ctx):
                 bias = rng.standard_normal(N).astype(np.float32)
                 for epi in (6, 1, 2):
                     outs = []
-                    for tile in (128, 256):
+                    for tile in (128, 256, 64):
                         assert ctx.lib.wmdbg_set_gemm_tile(tile) == 0
                         C = np.full((M, N), 0.25, np.float32)
                         assert ctx.lib.wmdbg_gemm(ctx.handle, P(A), P(Wt), P(bias), P(C), M, N, K, epi) == 0
                         outs.append(C)
-                    assert np.array_equal(outs[0], outs[1]), (it, M, N, K, epi)
+                    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), (it, M, N, K, epi)
     finally:
         ctx.lib.wmdbg_set_gemm_tile(0)

@@ -3,7 +3,7 @@ whole call (front end + encoder + 224-token decode), min of 2 after a warm-up, f
 
     gc=N        unmasked lanes, preferred group size N (debug knob group_chunks; N = 128: one group up to 128 chunks)
     parts=P     P CU-masked sub-chip lanes (round 6: hipExtStreamCreateWithCUMask), a slice of the CUs of every XCD each
-    partsx=P    the same with whole XCDs per lane (lane_mask_kind = 1)
+    split=P     P groups of ceil(B / P) chunks on P UNMASKED lanes (= gc=ceil(B / P))
     product     the product's own rule (no knob)
 
     python tools/gpu_group_policy_probe.py [model] [B,B,...] [col,col,...]
@@ -33,16 +33,10 @@ def main():
     nmax = max(sizes)
     pcm = np.round(np.clip(0.1 * rng.standard_normal((nmax, 480000)), -1, 1) * 32767).astype(np.int16)
     prompt = [50258, 50259, 50359, 50363] if dims["n_vocab"] >= 51865 else [50257, 50362]
-    ctxs = {}
-
-    def ctx_for(kind):   # the CU masks are fixed when a lane's stream is created: one context per mask kind
-        if kind not in ctxs:
-            lib.wmdbg_set_tuning(b"lane_mask_kind", kind)
-            c = B.Context(dims, debug=True)
-            c.init_synthetic(20240928, matrix_gain=4.0)
-            c.finalize()
-            ctxs[kind] = (c, c.to_device(pcm))
-        return ctxs[kind]
+    ctx = B.Context(dims, debug=True)
+    ctx.init_synthetic(20240928, matrix_gain=4.0)
+    ctx.finalize()
+    dp = ctx.to_device(pcm)
 
     print("%s: audio-s/s of one call of B chunks by group policy (3 lanes available)" % model)
     print("B    " + "".join("%-13s" % c for c in cols))
@@ -51,19 +45,16 @@ def main():
         for col in cols:
             lib.wmdbg_set_tuning(b"group_chunks", 0)
             lib.wmdbg_set_tuning(b"lane_parts", 0)
-            kind = 0
             if col.startswith("gc="):
                 lib.wmdbg_set_tuning(b"group_chunks", int(col[3:]))
                 lib.wmdbg_set_tuning(b"lane_parts", 1)
-            elif col.startswith("partsx="):
-                kind = 1
-                lib.wmdbg_set_tuning(b"lane_parts", int(col[7:]))
+            elif col.startswith("split="):
+                lib.wmdbg_set_tuning(b"group_chunks", -(-nb // int(col[6:])))
+                lib.wmdbg_set_tuning(b"lane_parts", 1)
             elif col.startswith("parts="):
                 lib.wmdbg_set_tuning(b"lane_parts", int(col[6:]))
             else:
                 assert col == "product", col
-            ctx, dp = ctx_for(kind)
-            lib.wmdbg_set_tuning(b"lane_mask_kind", kind)
             best = None
             for i in range(3):
                 t0 = time.perf_counter()
@@ -76,9 +67,8 @@ def main():
             row += "%8.0f%s    " % (30.0 * nb / best, ok)
         print(row, flush=True)
     lib.wmdbg_set_tuning(b"reset", 0)
-    for c, dp in ctxs.values():
-        c.dev_free(dp)
-        c.close()
+    ctx.dev_free(dp)
+    ctx.close()
 
 
 if __name__ == "__main__":
