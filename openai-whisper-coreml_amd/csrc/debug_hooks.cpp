@@ -26,7 +26,7 @@ extern "C" int wmdbg_set_tuning(const char *key, int value) {
         {"gemm_tile", &g_wm_tuning.gemm_tile}, {"gemm_gm", &g_wm_tuning.gemm_gm}, {"no_early_stop", &g_wm_tuning.no_early_stop},
         {"xattn_no_deep", &g_wm_tuning.xattn_no_deep}, {"xattn_never_short", &g_wm_tuning.xattn_never_short},         {"logits_tn", &g_wm_tuning.logits_tn}, {"enc_attn_mfma_sum", &g_wm_tuning.enc_attn_mfma_sum},
         {"group_chunks", &g_wm_tuning.group_chunks}, {"argmax_rows_per_wg", &g_wm_tuning.argmax_rows_per_wg}, {"xattn_fuse_q", &g_wm_tuning.xattn_fuse_q}, {"xattn_pair_wg_max_pairs", &g_wm_tuning.xattn_pair_wg_max_pairs},
-        {"lane_parts", &g_wm_tuning.lane_parts}, {"lane_solo_cus", &g_wm_tuning.lane_solo_cus},
+        {"lane_parts", &g_wm_tuning.lane_parts}, {"lane_solo_cus", &g_wm_tuning.lane_solo_cus}, {"frontend_per_wave_twiddles", &g_wm_tuning.frontend_per_wave_twiddles},
     };
     if (strcmp(key, "reset") == 0) { g_wm_tuning = WmTuning(); return WM_OK; }
     for (auto &e : table)

@@ -221,6 +221,141 @@ __global__ __launch_bounds__(WPB * 64) void logmel_stage1(
     if (lane == 0 && vmax > (T)-1e29) atomicMax(gmax + chunk, enc_max(vmax));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the f32 fast path's stage 1 with the twiddle slices SHARED through LDS.  The template above has every wave
+// fetch its own B operands from the L2-resident tables -- 28 global loads per lane and k-step, the whole 179 KB table per 16
+// frames: 1.9 GB of L2 traffic per 56-chunk launch, which is what bound the kernel (453.9 us: a quarter of the exact-f32
+// MFMA rate its 700 MFMAs per 16 frames allow).  Here a workgroup is 8 waves = 128 frames; the 7-KiB slice of a k-step
+// (4 tables x 4 rows x 112 columns) is fetched ONCE per workgroup (448 x 16 bytes), double-buffered in LDS one k-step
+// ahead, and read by every wave as ds_read_b32 fragments (conflict-free: rows are 112 words apart, 112 mod 32 = 16); the
+// window is in LDS too.  Same A operands, same MFMA chains in the same order, same epilogue: bit-identical to the template
+// (test).  LDS: max(PCM span, power spectrum) + 2 slices + window = 124 KiB, one workgroup per CU, two waves per SIMD.
+constexpr int W8 = 8;                                   // waves per workgroup
+constexpr int FPB8 = 16 * W8;                           // 128 frames
+constexpr int SPAN8 = (FPB8 - 1) * WM_HOP + WM_N_FFT;   // 20 720 samples
+constexpr int SPAN8_LDS = SPAN8 + SPAN8 / 160 + 4;
+constexpr int PW8_LDS = W8 * 16 * PW_STRIDE;            // 26 752 words
+constexpr int MAIN8 = SPAN8_LDS > PW8_LDS ? SPAN8_LDS : PW8_LDS;
+constexpr int SLICE8 = 4 * 4 * TW_COLS;                 // 1 792 words per k-step
+constexpr int LDS8_WORDS = MAIN8 + 2 * SLICE8 + 404 + W8 * 16;
+constexpr int LDS8_BYTES = LDS8_WORDS * 4;
+
+__global__ __launch_bounds__(W8 * 64) void logmel_stage1_f32_lds(
+    const void *__restrict__ pcm, int pcm_dtype, int n_mels, const float *__restrict__ tw, const float *__restrict__ win,
+    const int *__restrict__ band_start, const int *__restrict__ band_len, const float *__restrict__ band_w,
+    float *__restrict__ out, unsigned long long *__restrict__ gmax, int blocks_per_chunk) {
+    extern __shared__ __attribute__((aligned(16))) float smem8[];
+    float *xs = smem8;
+    float(*pw)[16][PW_STRIDE] = (float(*)[16][PW_STRIDE])smem8;
+    float *slice = smem8 + MAIN8;               // [2][4 tables][4 rows][112]
+    float *wl = slice + 2 * SLICE8;             // window, 401 values
+    int(*bad)[16] = (int(*)[16])(wl + 404);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < W8 * 16) bad[tid >> 4][tid & 15] = 0;
+    const int chunk = blockIdx.x / blocks_per_chunk;
+    const int f0 = (blockIdx.x % blocks_per_chunk) * FPB8;
+    // slice 0 requested first (16 bytes per thread, threads 0 .. 447: table t = tid / 112, float4 tid % 112 of rows 4 kk .. + 3)
+    const bool loader = tid < 448;
+    const float *tsrc = tw + (size_t)(tid / 112) * TW_ROWS * TW_COLS + (tid % 112) * 4;
+    float4 tnext = loader ? *(const float4 *)tsrc : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i <= 400; i += W8 * 64) wl[i] = win[i];
+    // ---- stage the PCM span (reflect pad by index; lib.rs:34-40) -----------------------
+    const size_t chunk_base = (size_t)chunk * WM_N_SAMPLES;
+    for (int i = tid; i < SPAN8; i += W8 * 64) {
+        int n = f0 * WM_HOP + i - 200;
+        if (n < 0) n = -n;
+        if (n >= WM_N_SAMPLES) n = 2 * (WM_N_SAMPLES - 1) - n;
+        if (n < 0) n = 0;                                  // only for masked frames >= 3000
+        xs[i + i / 160] = load_sample<float>(pcm, pcm_dtype, chunk_base + n);
+    }
+    if (loader) *(float4 *)(slice + tid * 4) = tnext;
+    __syncthreads();
+
+    typedef Acc<float>::type acc_t;
+    acc_t acc[4][NJT];  // Ce, Co, Se, So
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < NJT; ++j) acc[t][j] = (acc_t){0, 0, 0, 0};
+    const int fr = wave * 16 + (lane & 15);
+    const int kq = lane >> 4, col = lane & 15;
+    for (int kk = 0; kk < TW_ROWS / 4; ++kk) {
+        if (loader && kk + 1 < TW_ROWS / 4) tnext = *(const float4 *)(tsrc + (size_t)(kk + 1) * 4 * TW_COLS);
+        const int ie = 4 * kk + kq;
+        const int ne = 2 * (ie + 1), no = 2 * ie + 1;
+        const float x1e = xs[span_addr(fr, ne)], x2e = xs[span_addr(fr, WM_N_FFT - ne)];
+        const float x1o = xs[span_addr(fr, no)], x2o = xs[span_addr(fr, WM_N_FFT - no)];
+        const float we = wl[ne], wo = wl[no];
+        const float a_ce = we * ((ne == 200) ? x1e : (x1e + x2e));
+        const float a_se = we * (x1e - x2e);
+        const float a_co = wo * (x1o + x2o);
+        const float a_so = wo * (x1o - x2o);
+        const float *row = slice + (kk & 1) * SLICE8 + kq * TW_COLS + col;
+#pragma unroll
+        for (int j = 0; j < NJT; ++j) {
+            acc[0][j] = mfma4(a_ce, row[0 * 4 * TW_COLS + j * 16], acc[0][j]);
+            acc[1][j] = mfma4(a_co, row[1 * 4 * TW_COLS + j * 16], acc[1][j]);
+            acc[2][j] = mfma4(a_se, row[2 * 4 * TW_COLS + j * 16], acc[2][j]);
+            acc[3][j] = mfma4(a_so, row[3 * 4 * TW_COLS + j * 16], acc[3][j]);
+        }
+        // the next slice goes into the OTHER buffer (read in k-step kk - 1: everybody passed the barrier since)
+        if (loader && kk + 1 < TW_ROWS / 4) *(float4 *)(slice + ((kk + 1) & 1) * SLICE8 + tid * 4) = tnext;
+        __syncthreads();
+    }
+    // (the loop's last barrier: every wave is done with the PCM span -- its LDS becomes the power spectrum)
+#pragma unroll
+    for (int j = 0; j < NJT; ++j) {
+        const int k = j * 16 + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ce = acc[0][j][r], co = acc[1][j][r], se = acc[2][j][r], so = acc[3][j][r];
+            const int row = acc_row(0.f, lane, r);
+            int nbad = 0;
+            if (k <= 100) {
+                const float re = ce + co, im = se + so;
+                const float pv = re * re + im * im;
+                pw[wave][row][k] = pv;
+                nbad += !(pv - pv == 0.f);
+            }
+            if (k < 100) {
+                const float re = ce - co, im = so - se;
+                const float pv = re * re + im * im;
+                pw[wave][row][200 - k] = pv;
+                nbad += !(pv - pv == 0.f);
+            }
+            if (nbad) atomicAdd(&bad[wave][row], nbad);
+        }
+    }
+    __syncthreads();
+    const int frame = f0 + wave * 16 + (lane & 15);
+    const bool live = frame < WM_N_FRAMES;
+    float vmax = -1e30f;
+    for (int m = lane >> 4; m < n_mels; m += 4) {
+        const int ks = band_start[m], kl = band_len[m];
+        const float *wrow = band_w + m * WM_MEL_MAXW;
+        float s = 0;
+        int inband = 0;
+        for (int t = 0; t < kl; ++t) {
+            const float pv = pw[wave][lane & 15][ks + t];
+            s += pv * wrow[t];
+            inband += !(pv - pv == 0.f);
+        }
+        if (bad[wave][lane & 15] > inband) s = 0.f;
+        s = (s > 1e-10f) ? s : 1e-10f;
+        const float v = log10_t(s);
+        if (live) {
+            out[((size_t)chunk * n_mels + m) * WM_N_FRAMES + frame] = v;
+            vmax = (v > vmax) ? v : vmax;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(vmax, off);
+        vmax = (o > vmax) ? o : vmax;
+    }
+    if (lane == 0 && vmax > -1e29f) atomicMax(gmax + chunk, enc_max(vmax));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void logmel_stage2(T *__restrict__ io,
                                                      const unsigned long long *__restrict__ gmax,
@@ -381,13 +516,26 @@ int wm_frontend_run(WmFrontend *fe, WmProfiler *prof, hipStream_t stream, const 
     const size_t total = (size_t)n_chunks * n_mels * WM_N_FRAMES;
     const int g2 = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (out_dtype == WM_F32) {
-        constexpr int WPB = 4;
-        const int bpc = (WM_N_FRAMES + 16 * WPB - 1) / (16 * WPB);
-        {
+        if (g_wm_tuning.frontend_per_wave_twiddles) {   // probes / the bit-identity test: the round-1-5 kernel
+            constexpr int WPB = 4;
+            const int bpc = (WM_N_FRAMES + 16 * WPB - 1) / (16 * WPB);
             WmProfScope ps(prof, "logmel_stage1_f32", stream);
             logmel_stage1<float, WPB><<<n_chunks * bpc, WPB * 64, 0, stream>>>(
                 d_pcm, (int)pcm_dtype, n_mels, fe->cos32, fe->sin32, fe->win32, fe->band_start[fi],
                 fe->band_len[fi], fe->band_w[fi], (float *)d_out, (unsigned long long *)fe->gmax, bpc);
+        } else {
+            static std::atomic<int> attr_set[64];   // per device: the kernel's dynamic-LDS allowance is set once
+            int dev = 0;
+            WM_HIP(hipGetDevice(&dev));
+            if (!attr_set[dev & 63].load(std::memory_order_acquire)) {
+                WM_HIP(hipFuncSetAttribute((const void *)logmel_stage1_f32_lds, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8_BYTES));
+                attr_set[dev & 63].store(1, std::memory_order_release);
+            }
+            const int bpc = (WM_N_FRAMES + FPB8 - 1) / FPB8;
+            WmProfScope ps(prof, "logmel_stage1_f32", stream);
+            logmel_stage1_f32_lds<<<n_chunks * bpc, W8 * 64, LDS8_BYTES, stream>>>(
+                d_pcm, (int)pcm_dtype, n_mels, fe->cos32, fe->win32, fe->band_start[fi], fe->band_len[fi],
+                fe->band_w[fi], (float *)d_out, (unsigned long long *)fe->gmax, bpc);
         }
         {
             WmProfScope ps(prof, "logmel_stage2_f32", stream);

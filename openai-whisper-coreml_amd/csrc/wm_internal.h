@@ -192,6 +192,7 @@ struct WmTuning {
     int xattn_fuse_q = 1;         // 96 .. 256 pairs, alone: query projection fused into the cross-attention launch (0: two launches)
     int argmax_rows_per_wg = 0;   // PROBE: rows per workgroup of the step-closing arg-max (0 = the product's rule: 1, or 16 for <= 16 rows with early stop)
     int group_chunks = 0;         // preferred decode-group size of a wm_transcribe_greedy call (product rule: model_api.cpp)
+    int frontend_per_wave_twiddles = 0;   // 1: the f32 front end's round-1-5 stage-1 kernel (every wave fetches its own twiddles from L2)
     int lane_parts = 0;           // sub-chip lanes: 0 = the product's rule, 1 = never, 2 / 3 = that many CU-masked groups whenever the call has >= 2 chunks per part
     int lane_solo_cus = 0;        // PROBE: n in 1 .. 31 = run the call's decode groups one after the other on ONE lane confined to the first n CUs of every XCD
 };

@@ -146,8 +146,9 @@ def synthetic_state_dict(dims, seed=0, matrix_gain=1.0):
 # tools/gpu_lively_gain_probe.py (profiles/r06_lively_gain.txt): the smallest tried gain at which 32 distinct recordings --
 # seeded noise, and tones + noise -- decode to (all but at most one of) 32 distinct rows.  (A larger gain is a harsher numerical
 # test, not a livelier model: bf16 operand rounding grows with it -- tiny.en's 4-layer encoder is 5.3e-3 rel-L2 from the fp32
-# oracle at gain 8 -- so the smallest adequate gain is the one recorded.)
-LIVELY_GAIN_BY_WIDTH = {384: 6.0, 512: 12.0, 768: 6.0, 1024: 4.0, 1280: 4.0}
+# oracle at gain 8, base's 6-layer one 2.2e-2 at gain 12 (attention so peaked that an operand rounding flips its targets) --
+# so the smallest adequate gain is the one recorded: 6 below d = 1024 (31 - 32 distinct rows of 32), 4 from there.)
+LIVELY_GAIN_BY_WIDTH = {384: 6.0, 512: 6.0, 768: 6.0, 1024: 4.0, 1280: 4.0}
 
 
 def lively_gain(dims):

@@ -225,3 +225,31 @@ def test_generate_spectrogram_is_reentrant_under_concurrent_callers(pkg, oracle_
     [t.start() for t in th]
     [t.join() for t in th]
     assert all(e is not None and e <= 1e-9 for e in errs), errs
+
+
+def test_f32_stage1_with_shared_twiddles_is_bit_identical_to_the_per_wave_kernel(pkg):
+    """Round 6: the f32 fast path's stage 1 shares each k-step's twiddle slice through LDS (8-wave workgroups of 128 frames,
+    one 7-KiB fetch per workgroup and k-step instead of 28 global loads per lane: frontend.hip logmel_stage1_f32_lds).  Same A
+    operands, same MFMA chains in the same order: the output must equal the round-1-5 kernel's (debug knob
+    frontend_per_wave_twiddles) BIT FOR BIT -- 80 and 128 mel bins, int16 / f32 input, 1 / 3 / 9 chunks (24 workgroups per
+    chunk, the last one holding the masked frames >= 3000), non-finite samples included."""
+    lib = pkg.binding.load_debug_library()
+    lib.wmdbg_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    ctx = pkg.binding.Context(debug=True)
+    try:
+        for n, n_mels, dt in ((1, 80, np.float32), (3, 128, np.int16), (9, 80, np.int16)):
+            pcm = np.stack([L.synth_chunk(40 + i) for i in range(n)]).astype(np.float32)
+            if n == 1:
+                pcm[0, 1000] = np.inf          # a non-finite sample (f32 input): the 0 x Inf rule of the dense mel product
+            if n == 3:
+                pcm[2, 479000:] = 0
+            x = np.round(pcm * 32767).astype(np.int16) if dt == np.int16 else pcm
+            outs = []
+            for knob in (0, 1):
+                assert lib.wmdbg_set_tuning(b"frontend_per_wave_twiddles", knob) == 0
+                outs.append(ctx.logmel(x, n_mels=n_mels, out_dtype=np.float32))
+            assert outs[0].shape == (n, n_mels, 3000)
+            assert np.array_equal(outs[0], outs[1], equal_nan=True), (n, n_mels, dt)
+    finally:
+        lib.wmdbg_set_tuning(b"reset", 0)
+        ctx.close()
