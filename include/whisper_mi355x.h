@@ -172,12 +172,20 @@ WM_API int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_dtype
 
 /* Decode groups a wm_transcribe_greedy call on this context keeps in flight.
  *   0 (default): the library's own measured policy -- one group below 32 chunks, two groups (two weight-sharing lanes)
- *                up to 143, three from 144 chunks, never more than $WM_LANES (default 3) at once;
+ *                up to 143, three from 144 chunks, never more than $WM_LANES (default 3) at once; for the NARROW models
+ *                (decoder width <= 512: tiny, base) the two groups of a 24 .. 128-chunk call (tiny: 32 .. 47) run on two
+ *                SUB-CHIP lanes -- streams confined by a CU mask to complementary halves of every XCD's CUs (round 6:
+ *                +2 .. +9 % there; a wide model's decode needs all the CUs and is never split this way);
  *   1          : the whole call (up to 128 chunks) is ONE decode group on the context's own stream -- what a host that runs
  *                its own concurrency over wm_clone'd contexts wants (bench.py);
  *   n = 2 .. 8 : n groups in flight whenever the call has 8 chunks for each (groups of ~8 up to 8 n chunks, n balanced
  *                groups of up to 128 beyond): a host that knows its latency / throughput trade-off better than the default.
- * Tokens do not depend on the choice (bit-level batch invariance). */
+ * Tokens do not depend on the choice (bit-level batch invariance).
+ * EARLY STOP TRADE-OFF (eot >= 0 or wm_set_token_budgets): a decode group runs until its LAST row is finished, so the
+ * default's single group below 32 chunks -- measured with fixed-length decodes, where it is the fastest cut -- decodes a
+ * 24-chunk call with one straggler for ~0.8 of a full decode, where three groups of 8 (wm_set_lanes(3)) would have
+ * spent ~0.6-0.7 (each group stops on its own).  A host whose utterance lengths vary widely and whose calls are 9 .. 31
+ * chunks may prefer wm_set_lanes(2) or (3); the default is tuned for throughput at fixed length. */
 WM_API int wm_set_lanes(wm_ctx *ctx, int n_lanes);
 
 /* Logit filters of openai-whisper's greedy decode() (whisper/decoding.py SuppressTokens and SuppressBlank; SURVEY.md 8f

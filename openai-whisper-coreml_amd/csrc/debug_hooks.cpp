@@ -23,7 +23,7 @@ extern "C" int wmdbg_set_tuning(const char *key, int value) {
         {"prefetch_max_b", &g_wm_tuning.prefetch_max_b}, {"xattn_split_below", &g_wm_tuning.xattn_split_below},
         {"xattn_wgs", &g_wm_tuning.xattn_wgs}, {"xattn_no_flat", &g_wm_tuning.xattn_no_flat},
         {"xattn_lds_pad", &g_wm_tuning.xattn_lds_pad}, {"xattn_splits", &g_wm_tuning.xattn_splits},
-        {"gemm_tile", &g_wm_tuning.gemm_tile}, {"gemm_gm", &g_wm_tuning.gemm_gm}, {"no_early_stop", &g_wm_tuning.no_early_stop},
+        {"gemm_tile", &g_wm_tuning.gemm_tile}, {"gemm128_pipe", &g_wm_tuning.gemm128_pipe}, {"gemm_gm", &g_wm_tuning.gemm_gm}, {"no_early_stop", &g_wm_tuning.no_early_stop},
         {"xattn_no_deep", &g_wm_tuning.xattn_no_deep}, {"xattn_never_short", &g_wm_tuning.xattn_never_short},         {"logits_tn", &g_wm_tuning.logits_tn}, {"enc_attn_mfma_sum", &g_wm_tuning.enc_attn_mfma_sum},
         {"group_chunks", &g_wm_tuning.group_chunks}, {"argmax_rows_per_wg", &g_wm_tuning.argmax_rows_per_wg}, {"xattn_fuse_q", &g_wm_tuning.xattn_fuse_q}, {"xattn_pair_wg_max_pairs", &g_wm_tuning.xattn_pair_wg_max_pairs},
         {"lane_parts", &g_wm_tuning.lane_parts}, {"lane_solo_cus", &g_wm_tuning.lane_solo_cus}, {"frontend_per_wave_twiddles", &g_wm_tuning.frontend_per_wave_twiddles},

@@ -62,7 +62,9 @@ __device__ __forceinline__ Acc<double>::type mfma4(double a, double b, Acc<doubl
 __device__ __forceinline__ int acc_row(float, int lane, int r) { return (lane >> 4) * 4 + r; }
 __device__ __forceinline__ int acc_row(double, int lane, int r) { return (lane >> 4) + 4 * r; }
 
-__device__ __forceinline__ float log10_t(float x) { return log10f(x); }
+// f32 path: log10 as log2 x log10(2) -- v_log_f32 (1 ulp) and one multiply instead of the ~30-instruction libm expansion, 20-32
+// times per lane; |error| <= 2e-7 relative, four orders below the path's 1e-4 gate (round 6; both f32 kernels share it)
+__device__ __forceinline__ float log10_t(float x) { return __builtin_amdgcn_logf(x) * 0.30102999566398120f; }
 __device__ __forceinline__ double log10_t(double x) { return log10(x); }
 
 // Monotone encodings so an unsigned atomicMax orders floating-point values.
@@ -225,28 +227,40 @@ __global__ __launch_bounds__(WPB * 64) void logmel_stage1(
 // Round 6: the f32 fast path's stage 1 with the twiddle slices SHARED through LDS.  The template above has every wave
 // fetch its own B operands from the L2-resident tables -- 28 global loads per lane and k-step, the whole 179 KB table per 16
 // frames: 1.9 GB of L2 traffic per 56-chunk launch, which is what bound the kernel (453.9 us: a quarter of the exact-f32
-// MFMA rate its 700 MFMAs per 16 frames allow).  Here a workgroup is 8 waves = 128 frames; the 7-KiB slice of a k-step
-// (4 tables x 4 rows x 112 columns) is fetched ONCE per workgroup (448 x 16 bytes), double-buffered in LDS one k-step
+// MFMA rate its 700 MFMAs per 16 frames allow).  Here the 7-KiB slice of a k-step (4 tables x 4 rows x 112 columns) is
+// fetched ONCE per workgroup of 4 waves = 64 frames (448 x 16 bytes), double-buffered in LDS one k-step
 // ahead, and read by every wave as ds_read_b32 fragments (conflict-free: rows are 112 words apart, 112 mod 32 = 16); the
 // window is in LDS too.  Same A operands, same MFMA chains in the same order, same epilogue: bit-identical to the template
-// (test).  LDS: max(PCM span, power spectrum) + 2 slices + window = 124 KiB, one workgroup per CU, two waves per SIMD.
-constexpr int W8 = 8;                                   // waves per workgroup
-constexpr int FPB8 = 16 * W8;                           // 128 frames
-constexpr int SPAN8 = (FPB8 - 1) * WM_HOP + WM_N_FFT;   // 20 720 samples
+// (test).  LDS: max(PCM span, power spectrum) + 2 slices + window + mel bands = 76.5 KiB: TWO workgroups per CU, so one's
+// power / mel / log epilogue (no matrix work) runs under the other's DFT, and 2 688 workgroups at 56 chunks are 5.25 rounds of
+// the chip instead of the 6 that 1 344 eight-wave ones were (the first version of this kernel: 303 us).
+// What the stall counters said the kernel was really waiting for (profiles/r06_pmc_frontend_stalls.txt: the matrix pipe busy
+// 22 % of a wave's life, 42 % parked at s_waitcnt) were two LATENCY chains outside the DFT, and both are gone here:
+//   * the PCM span was staged one 2-byte load per thread and pass, ~41 dependent HBM round trips per wave: now every thread
+//     requests its whole share up front as 16-byte loads (8 int16 / 4 f32 samples; the blocks that touch the reflect pad or
+//     the end of the chunk, 2 of 24, gather by index -- still all loads before the first store);
+//   * the mel loop fetched band start / length / weights from global memory per row (three dependent L2 round trips x 20-32
+//     rows per lane): the band tables are copied to LDS once per workgroup.
+constexpr int W8 = 4;                                   // waves per workgroup: 64 frames, TWO workgroups per CU (one's epilogue under the other's DFT)
+constexpr int FPB8 = 16 * W8;
+constexpr int SPAN8 = (FPB8 - 1) * WM_HOP + WM_N_FFT;   // 10 480 samples
 constexpr int SPAN8_LDS = SPAN8 + SPAN8 / 160 + 4;
-constexpr int PW8_LDS = W8 * 16 * PW_STRIDE;            // 26 752 words
+constexpr int PW8_STRIDE = 201;                         // odd (conflict-free column walks), >= 201 bins
+constexpr int PW8_LDS = W8 * 16 * PW8_STRIDE;           // 12 864 words
 constexpr int MAIN8 = SPAN8_LDS > PW8_LDS ? SPAN8_LDS : PW8_LDS;
 constexpr int SLICE8 = 4 * 4 * TW_COLS;                 // 1 792 words per k-step
-constexpr int LDS8_WORDS = MAIN8 + 2 * SLICE8 + 404 + W8 * 16;
-constexpr int LDS8_BYTES = LDS8_WORDS * 4;
+constexpr int BW8 = 16;                                 // band weights kept per mel row in LDS (80 mels: <= 14, 128 mels: <= 10; checked by the host)
+constexpr int BAND8 = 128 * (BW8 + 2);                  // band start / length / weights of up to 128 mel rows
+constexpr int LDS8_WORDS = MAIN8 + 2 * SLICE8 + 404 + W8 * 16 + BAND8;
+constexpr int LDS8_BYTES = LDS8_WORDS * 4;              // 76.5 KiB: two workgroups per CU
 
-__global__ __launch_bounds__(W8 * 64) void logmel_stage1_f32_lds(
+__global__ __launch_bounds__(W8 * 64, 2) void logmel_stage1_f32_lds(
     const void *__restrict__ pcm, int pcm_dtype, int n_mels, const float *__restrict__ tw, const float *__restrict__ win,
     const int *__restrict__ band_start, const int *__restrict__ band_len, const float *__restrict__ band_w,
     float *__restrict__ out, unsigned long long *__restrict__ gmax, int blocks_per_chunk) {
     extern __shared__ __attribute__((aligned(16))) float smem8[];
     float *xs = smem8;
-    float(*pw)[16][PW_STRIDE] = (float(*)[16][PW_STRIDE])smem8;
+    float(*pw)[16][PW8_STRIDE] = (float(*)[16][PW8_STRIDE])smem8;
     float *slice = smem8 + MAIN8;               // [2][4 tables][4 rows][112]
     float *wl = slice + 2 * SLICE8;             // window, 401 values
     int(*bad)[16] = (int(*)[16])(wl + 404);
@@ -254,21 +268,77 @@ __global__ __launch_bounds__(W8 * 64) void logmel_stage1_f32_lds(
     if (tid < W8 * 16) bad[tid >> 4][tid & 15] = 0;
     const int chunk = blockIdx.x / blocks_per_chunk;
     const int f0 = (blockIdx.x % blocks_per_chunk) * FPB8;
-    // slice 0 requested first (16 bytes per thread, threads 0 .. 447: table t = tid / 112, float4 tid % 112 of rows 4 kk .. + 3)
-    const bool loader = tid < 448;
-    const float *tsrc = tw + (size_t)(tid / 112) * TW_ROWS * TW_COLS + (tid % 112) * 4;
-    float4 tnext = loader ? *(const float4 *)tsrc : make_float4(0.f, 0.f, 0.f, 0.f);
+    // slice 0 requested first: 448 x 16 bytes (element e: table t = e / 112, float4 e % 112 of rows 4 kk .. + 3), thread tid
+    // fetches elements tid and tid + 256
+    const bool loader2 = tid + 256 < 448;
+    const float *tsrc0 = tw + (size_t)(tid / 112) * TW_ROWS * TW_COLS + (tid % 112) * 4;
+    const float *tsrc1 = tw + (size_t)((tid + 256) / 112) * TW_ROWS * TW_COLS + ((tid + 256) % 112) * 4;
+    float4 tnext0 = *(const float4 *)tsrc0;
+    float4 tnext1 = loader2 ? *(const float4 *)tsrc1 : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = tid; i <= 400; i += W8 * 64) wl[i] = win[i];
-    // ---- stage the PCM span (reflect pad by index; lib.rs:34-40) -----------------------
+    float *bnd = (float *)(bad + W8);           // [n_mels] start | [n_mels] length (as ints) | [n_mels][BW8] weights
+    int *bnd_i = (int *)bnd;
+    for (int i = tid; i < n_mels; i += W8 * 64) { bnd_i[i] = band_start[i]; bnd_i[128 + i] = band_len[i]; }
+    for (int i = tid; i < n_mels * BW8; i += W8 * 64) bnd[256 + i] = band_w[(i / BW8) * WM_MEL_MAXW + (i % BW8)];
+    // ---- stage the PCM span (reflect pad by index; lib.rs:34-40): all loads of a thread first, then its stores ----------
     const size_t chunk_base = (size_t)chunk * WM_N_SAMPLES;
-    for (int i = tid; i < SPAN8; i += W8 * 64) {
-        int n = f0 * WM_HOP + i - 200;
-        if (n < 0) n = -n;
-        if (n >= WM_N_SAMPLES) n = 2 * (WM_N_SAMPLES - 1) - n;
-        if (n < 0) n = 0;                                  // only for masked frames >= 3000
-        xs[i + i / 160] = load_sample<float>(pcm, pcm_dtype, chunk_base + n);
+    constexpr int PER = 8, NPASS = (SPAN8 / PER + W8 * 64 - 1) / (W8 * 64);   // 1310 groups of 8 samples, 6 passes of 256 threads
+    static_assert(SPAN8 % PER == 0, "the span is a whole number of 8-sample groups");
+    const int first = f0 * WM_HOP - 200;        // unpadded-chunk index of span sample 0
+    // (workgroup-uniform) no reflect, no masked frames -- and a caller's buffer that is 16-byte aligned (chunk offsets and
+    // `first` are multiples of 16 bytes for int16 and f32; an odd base pointer takes the gather path)
+    const bool interior = first >= 0 && first + SPAN8 <= WM_N_SAMPLES && ((size_t)pcm & 15) == 0;
+    float v[NPASS][PER];
+    if (interior && pcm_dtype == WM_I16) {      // 16 bytes = 8 samples per load; first * 2 and chunk_base * 2 are multiples of 16
+        const short *src = (const short *)pcm + chunk_base + first;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int g = ps * W8 * 64 + tid;
+            const uint4 raw = g * PER < SPAN8 ? *(const uint4 *)(src + g * PER) : make_uint4(0, 0, 0, 0);
+            const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[ps][2 * u] = (float)(short)(w[u] & 0xffffu) * (float)(1.0 / 32768.0);
+                v[ps][2 * u + 1] = (float)(short)(w[u] >> 16) * (float)(1.0 / 32768.0);
+            }
+        }
+    } else if (interior && pcm_dtype == WM_F32) {
+        const float *src = (const float *)pcm + chunk_base + first;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int g = ps * W8 * 64 + tid;
+            const bool ok = g * PER < SPAN8;
+            const float4 a = ok ? *(const float4 *)(src + g * PER) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 b = ok ? *(const float4 *)(src + g * PER + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[ps][0] = a.x; v[ps][1] = a.y; v[ps][2] = a.z; v[ps][3] = a.w;
+            v[ps][4] = b.x; v[ps][5] = b.y; v[ps][6] = b.z; v[ps][7] = b.w;
+        }
+    } else {                                    // edge blocks / f64 input: gather by (reflected) index
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int g = ps * W8 * 64 + tid;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                int n = first + g * PER + u;
+                if (n < 0) n = -n;                                 // a[i] = a[400 - i]
+                if (n >= WM_N_SAMPLES) n = 2 * (WM_N_SAMPLES - 1) - n;  // a[j] = a[200 + (N-2) - i]
+                if (n < 0) n = 0;                                  // only for masked frames >= 3000
+                if (n >= WM_N_SAMPLES) n = WM_N_SAMPLES - 1;       // (groups past the span: never stored)
+                v[ps][u] = load_sample<float>(pcm, pcm_dtype, chunk_base + n);
+            }
+        }
     }
-    if (loader) *(float4 *)(slice + tid * 4) = tnext;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int i0 = (ps * W8 * 64 + tid) * PER;
+        if (i0 < SPAN8) {
+            const int q = i0 / 160, r = i0 - q * 160;   // pad word per 160 samples: i + i / 160
+#pragma unroll
+            for (int u = 0; u < PER; ++u) xs[i0 + u + q + (r + u >= 160 ? 1 : 0)] = v[ps][u];
+        }
+    }
+    *(float4 *)(slice + tid * 4) = tnext0;
+    if (loader2) *(float4 *)(slice + (tid + 256) * 4) = tnext1;
     __syncthreads();
 
     typedef Acc<float>::type acc_t;
@@ -280,7 +350,10 @@ __global__ __launch_bounds__(W8 * 64) void logmel_stage1_f32_lds(
     const int fr = wave * 16 + (lane & 15);
     const int kq = lane >> 4, col = lane & 15;
     for (int kk = 0; kk < TW_ROWS / 4; ++kk) {
-        if (loader && kk + 1 < TW_ROWS / 4) tnext = *(const float4 *)(tsrc + (size_t)(kk + 1) * 4 * TW_COLS);
+        if (kk + 1 < TW_ROWS / 4) {
+            tnext0 = *(const float4 *)(tsrc0 + (size_t)(kk + 1) * 4 * TW_COLS);
+            if (loader2) tnext1 = *(const float4 *)(tsrc1 + (size_t)(kk + 1) * 4 * TW_COLS);
+        }
         const int ie = 4 * kk + kq;
         const int ne = 2 * (ie + 1), no = 2 * ie + 1;
         const float x1e = xs[span_addr(fr, ne)], x2e = xs[span_addr(fr, WM_N_FFT - ne)];
@@ -299,7 +372,10 @@ __global__ __launch_bounds__(W8 * 64) void logmel_stage1_f32_lds(
             acc[3][j] = mfma4(a_so, row[3 * 4 * TW_COLS + j * 16], acc[3][j]);
         }
         // the next slice goes into the OTHER buffer (read in k-step kk - 1: everybody passed the barrier since)
-        if (loader && kk + 1 < TW_ROWS / 4) *(float4 *)(slice + ((kk + 1) & 1) * SLICE8 + tid * 4) = tnext;
+        if (kk + 1 < TW_ROWS / 4) {
+            *(float4 *)(slice + ((kk + 1) & 1) * SLICE8 + tid * 4) = tnext0;
+            if (loader2) *(float4 *)(slice + ((kk + 1) & 1) * SLICE8 + (tid + 256) * 4) = tnext1;
+        }
         __syncthreads();
     }
     // (the loop's last barrier: every wave is done with the PCM span -- its LDS becomes the power spectrum)
@@ -331,8 +407,8 @@ __global__ __launch_bounds__(W8 * 64) void logmel_stage1_f32_lds(
     const bool live = frame < WM_N_FRAMES;
     float vmax = -1e30f;
     for (int m = lane >> 4; m < n_mels; m += 4) {
-        const int ks = band_start[m], kl = band_len[m];
-        const float *wrow = band_w + m * WM_MEL_MAXW;
+        const int ks = bnd_i[m], kl = bnd_i[128 + m];
+        const float *wrow = bnd + 256 + m * BW8;
         float s = 0;
         int inband = 0;
         for (int t = 0; t < kl; ++t) {
@@ -421,7 +497,8 @@ void wm_mel_filterbank(int n_mels, std::vector<float> &out) {
 }
 
 static int build_bands(const float *filt, int n_mels, int **d_start, int **d_len, float **d_w,
-                       hipStream_t s) {
+                       hipStream_t s, int *max_w) {
+    *max_w = 0;
     std::vector<int> st(n_mels), ln(n_mels);
     std::vector<float> w((size_t)n_mels * WM_MEL_MAXW, 0.0f);
     for (int m = 0; m < n_mels; ++m) {
@@ -438,6 +515,7 @@ static int build_bands(const float *filt, int n_mels, int **d_start, int **d_len
         WM_REQUIRE(hi - lo + 1 <= WM_MEL_MAXW, WM_ERR_INVALID, "mel band %d too wide", m);
         st[m] = lo;
         ln[m] = hi - lo + 1;
+        if (ln[m] > *max_w) *max_w = ln[m];
         for (int k = lo; k <= hi; ++k) w[(size_t)m * WM_MEL_MAXW + (k - lo)] = filt[m * WM_N_BINS + k];
     }
     WM_TRY(upload(d_start, st, s));
@@ -477,11 +555,11 @@ int wm_frontend_init(WmFrontend *fe, hipStream_t stream) {
     WM_TRY(upload(&fe->cos32, c32, stream));
     WM_TRY(upload(&fe->sin32, s32, stream));
     WM_TRY(upload(&fe->win32, w32, stream));
-    WM_TRY(build_bands(kMel80, 80, &fe->band_start[0], &fe->band_len[0], &fe->band_w[0], stream));
+    WM_TRY(build_bands(kMel80, 80, &fe->band_start[0], &fe->band_len[0], &fe->band_w[0], stream, &fe->band_maxw[0]));
     std::vector<float> m128;
     wm_mel_filterbank(128, m128);
     WM_TRY(build_bands(m128.data(), 128, &fe->band_start[1], &fe->band_len[1], &fe->band_w[1],
-                       stream));
+                       stream, &fe->band_maxw[1]));
     fe->ready = true;
     return WM_OK;
 }
@@ -516,7 +594,7 @@ int wm_frontend_run(WmFrontend *fe, WmProfiler *prof, hipStream_t stream, const 
     const size_t total = (size_t)n_chunks * n_mels * WM_N_FRAMES;
     const int g2 = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (out_dtype == WM_F32) {
-        if (g_wm_tuning.frontend_per_wave_twiddles) {   // probes / the bit-identity test: the round-1-5 kernel
+        if (g_wm_tuning.frontend_per_wave_twiddles || fe->band_maxw[fi] > BW8) {   // probes / the bit-identity test: the round-1-5 kernel (also: a filterbank with bands wider than the LDS copy holds)
             constexpr int WPB = 4;
             const int bpc = (WM_N_FRAMES + 16 * WPB - 1) / (16 * WPB);
             WmProfScope ps(prof, "logmel_stage1_f32", stream);

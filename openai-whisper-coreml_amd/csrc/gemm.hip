@@ -21,6 +21,7 @@
 //     of an output frame is a CONTIGUOUS run of 3*C elements.
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "model.h"
@@ -529,6 +530,126 @@ __global__ __launch_bounds__(256, 2) void gemm64_bf16_kernel(GemmDev p) {
 }
 
 // =================================================================================================
+// The 128 x 128 tile as a 3-stage LDS-DMA pipeline (round 6): same tile, same wave layout, same epilogues as
+// gemm_bf16_kernel above, but K-tiles are streamed TWO ahead of the one being multiplied (ring of 3 x 32 KiB, counted
+// s_waitcnt vmcnt(8), one barrier per K-tile, inline-asm ds_reads) instead of double-buffered with a full drain per
+// K-tile.  For grids of at most one workgroup per CU (160-256 tiles: the N = d products of two 30 s chunks at large-v2,
+// the QKV product of Whisper-small x 1) nothing else hides the LDS-DMA round trip; 96 KiB of LDS = one workgroup per CU, so
+// larger grids keep the two-per-CU double-buffer kernel.  Same accumulation order: bitwise equal (test).
+constexpr int NST2 = 3;
+constexpr int STAGE2_BYTES = 2 * TILE_BYTES;   // A + W of one K-tile: 32 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm128p_bf16_kernel(GemmDev p) {
+    extern __shared__ __attribute__((aligned(1024))) char lds_dyn[];   // NST2 * STAGE2_BYTES
+    char *lds = lds_dyn;
+    int tm, tn;
+    tile_of_workgroup(p, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int srow = tid >> 3, pch = tid & 7;
+    const bf16_t *a_src[4];
+    const bf16_t *w_src[4];
+    const unsigned arpb = p.a_rpb > 0x7fffffffL ? 0x7fffffffu : (unsigned)p.a_rpb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = i * 32 + srow;
+        const int lch = pch ^ (row & 7);
+        unsigned m = (unsigned)(m0 + row);
+        if (m > (unsigned)(p.M - 1)) m = (unsigned)(p.M - 1);  // clamp: tail rows are masked in the epilogue
+        const unsigned aq = m / arpb, ar = m - aq * arpb;
+        a_src[i] = p.A + (long)aq * p.a_bstride + (long)ar * p.a_rstride + lch * 8;
+        long n = n0 + row;
+        if (n > p.N - 1) n = p.N - 1;
+        w_src[i] = p.W + n * (long)p.K + lch * 8;
+    }
+    const int nk = p.K / BK;
+    auto stage = [&](int slot, int kt) {   // 8 LDS-DMA instructions per wave
+        const long ko = (long)(kt < nk ? kt : nk - 1) * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            char *da = lds + slot * STAGE2_BYTES + (i * 32 + wave * 8) * 128;   // wave-uniform base; the hardware adds lane * 16
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a_src[i] + ko),
+                                             (__attribute__((address_space(3))) void *)da, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(w_src[i] + ko),
+                                             (__attribute__((address_space(3))) void *)(da + TILE_BYTES), 16, 0, 0);
+        }
+    };
+    const int frow = lane & 15, fq = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+    unsigned aa[4][2], wa[4][2];   // [fragment][k-step], slot 0 (slots 1 / 2: + 32 KiB as an immediate / in a second address set:
+                                   // a ds_read immediate is 16 bits)
+    unsigned aa2[4][2], wa2[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ra = wr * 64 + i * 16 + frow, rb = wc * 64 + i * 16 + frow;
+            aa[i][ks] = lds0 + (unsigned)(ra * 128 + (((ks * 4 + fq) ^ (ra & 7)) << 4));
+            wa[i][ks] = lds0 + (unsigned)(rb * 128 + (((ks * 4 + fq) ^ (rb & 7)) << 4));
+            aa2[i][ks] = aa[i][ks] + 2u * STAGE2_BYTES;
+            wa2[i][ks] = wa[i][ks] + 2u * STAGE2_BYTES;
+        }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    stage(0, 0);
+    stage(1, 1);
+    auto step = [&](int kt, auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        constexpr int SO = SLOT == 2 ? 0 : SLOT * STAGE2_BYTES;
+        auto &A_ = SLOT == 2 ? aa2 : aa;
+        auto &W_ = SLOT == 2 ? wa2 : wa;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // this wave's pieces of K-tile kt have landed (kt + 1 may be in flight)
+        __builtin_amdgcn_s_barrier();                        // ... everybody's; and everybody is done reading K-tile kt - 1
+        stage((SLOT + 2) % NST2, kt + 2);                    // into the slot K-tile kt - 1 lived in
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], bfr[4];
+            WM_DSR3(af[0], A_[0][ks], SO); WM_DSR3(af[1], A_[1][ks], SO); WM_DSR3(af[2], A_[2][ks], SO); WM_DSR3(af[3], A_[3][ks], SO);
+            WM_DSR3(bfr[0], W_[0][ks], SO + TILE_BYTES); WM_DSR3(bfr[1], W_[1][ks], SO + TILE_BYTES);
+            WM_DSR3(bfr[2], W_[2][ks], SO + TILE_BYTES); WM_DSR3(bfr[3], W_[3][ks], SO + TILE_BYTES);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]), "+v"(bfr[3])::"memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    int kt = 0;
+    for (; kt + 3 <= nk; kt += 3) {
+        step(kt, std::integral_constant<int, 0>{});
+        step(kt + 1, std::integral_constant<int, 1>{});
+        step(kt + 2, std::integral_constant<int, 2>{});
+    }
+    if (kt < nk) { step(kt, std::integral_constant<int, 0>{}); ++kt; }   // (workgroup-uniform remainders)
+    if (kt < nk) { step(kt, std::integral_constant<int, 1>{}); ++kt; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-requested tail tiles have landed ...
+    __builtin_amdgcn_s_barrier();                        // ... and nobody reads the operand tiles any more: LDS is the epilogues' now
+    if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_GELU_BF16 || EPI == EPI_QKV_ENC || EPI == EPI_XKV) {
+        const int nwave0 = n0 + wc * 64;
+        if (p.N % 64 == 0 && (EPI == EPI_XKV ? p.seq : p.c_rpb) >= 8 &&
+            !(EPI == EPI_QKV_ENC && nwave0 >= 2 * p.d_model)) {  // wave-uniform
+            store_tile_staged<EPI, 4, 4>(p, acc, m0 + wr * 64, nwave0, lds + wave * STAGE_WAVE_BYTES, lane);
+            return;
+        }
+    }
+    if constexpr (EPI == EPI_RESID_F32) {
+        if (p.N % 64 == 0 && p.c_rpb >= 8) {
+            resid_tile_staged<4, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, lds + wave * STAGE_WAVE_BYTES, lane);
+            return;
+        }
+    }
+    store_tile<EPI, 4, 4>(p, acc, m0 + wr * 64 + fq * 4, n0 + wc * 64 + frow);
+}
+
+// =================================================================================================
 // 256 x 256 x 64 tile for the large encoder products: 512 threads = 8 wave64 as 2(M) x 4(N), each wave
 // owns 128 x 64 of C (8 x 4 fragments, 128 accumulator registers); one workgroup per CU (128 KiB LDS).
 //
@@ -734,10 +855,20 @@ int wm_gemm_set_tile_override(int tile) {
 }
 
 template <int EPI>
-static void launch_gemm(const GemmDev &p, int tile, int grid, hipStream_t s) {
+static int launch_gemm(const GemmDev &p, int tile, bool pipe128, int grid, hipStream_t s) {
     if (tile == 256) gemm256_bf16_kernel<EPI><<<grid, 512, 0, s>>>(p);
-    else if (tile == 128) gemm_bf16_kernel<EPI><<<grid, 256, 0, s>>>(p);
+    else if (tile == 128 && pipe128) {
+        static std::atomic<int> attr_set[64];   // per device: the kernel's dynamic-LDS allowance (96 KiB) is set once
+        int dev = 0;
+        WM_HIP(hipGetDevice(&dev));
+        if (!attr_set[dev & 63].load(std::memory_order_acquire)) {
+            WM_HIP(hipFuncSetAttribute((const void *)gemm128p_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, NST2 * STAGE2_BYTES));
+            attr_set[dev & 63].store(1, std::memory_order_release);
+        }
+        gemm128p_bf16_kernel<EPI><<<grid, 256, NST2 * STAGE2_BYTES, s>>>(p);
+    } else if (tile == 128) gemm_bf16_kernel<EPI><<<grid, 256, 0, s>>>(p);
     else gemm64_bf16_kernel<EPI><<<grid, 256, 0, s>>>(p);
+    return WM_OK;
 }
 
 int wm_gemm(wm_ctx *ctx, const GemmArgs &g) {
@@ -763,19 +894,24 @@ int wm_gemm(wm_ctx *ctx, const GemmArgs &g) {
     p.tiles_m = (g.M + bm - 1) / bm;
     p.tiles_n = (g.N + bn - 1) / bn;
     const int grid = p.tiles_m * p.tiles_n;
+    // 128 tile: the 3-stage pipeline (96 KiB of LDS: ONE workgroup per CU) while the grid fits one round of the chip that way,
+    // the two-per-CU double buffer above that (measured, encoder per call: large-v2 x 2 chunks 7.64 -> 6.51 ms with its 240-tile
+    // N = d products on the pipeline; a 288- or 360-tile product is two rounds at one per CU and loses 3-6 %:
+    // profiles/r06_gemm128_pipeline_ab.txt).  (g_wm_tuning.gemm128_pipe: probes; 1 = never, 2 = always)
+    const bool pipe128 = g_wm_tuning.gemm128_pipe == 2 || (g_wm_tuning.gemm128_pipe == 0 && grid <= ctx->n_cus);
     p.group_m = g_wm_tuning.gemm_gm > 0 ? g_wm_tuning.gemm_gm : 4;  // measured at large-v2, B = 8: GM 1 / 4 / 8 / 16 -> fc1 341 / 328 / 335 / 335 us
     static const char *names[] = {"gemm_bias_bf16", "gemm_gelu_bf16", "gemm_resid_f32", "gemm_conv2_f32",
                                   "gemm_qkv_enc", "gemm_xkv", "gemm_f32"};
     WmProfScope ps(&ctx->prof, names[g.epi], ctx->stream);
     hipStream_t st = ctx->stream;
     switch (g.epi) {
-        case EPI_BIAS_BF16: launch_gemm<EPI_BIAS_BF16>(p, tile, grid, st); break;
-        case EPI_GELU_BF16: launch_gemm<EPI_GELU_BF16>(p, tile, grid, st); break;
-        case EPI_RESID_F32: launch_gemm<EPI_RESID_F32>(p, tile, grid, st); break;
-        case EPI_CONV2_F32: launch_gemm<EPI_CONV2_F32>(p, tile, grid, st); break;
-        case EPI_QKV_ENC: launch_gemm<EPI_QKV_ENC>(p, tile, grid, st); break;
-        case EPI_XKV: launch_gemm<EPI_XKV>(p, tile, grid, st); break;
-        case EPI_F32: launch_gemm<EPI_F32>(p, tile, grid, st); break;
+        case EPI_BIAS_BF16: WM_TRY(launch_gemm<EPI_BIAS_BF16>(p, tile, pipe128, grid, st)); break;
+        case EPI_GELU_BF16: WM_TRY(launch_gemm<EPI_GELU_BF16>(p, tile, pipe128, grid, st)); break;
+        case EPI_RESID_F32: WM_TRY(launch_gemm<EPI_RESID_F32>(p, tile, pipe128, grid, st)); break;
+        case EPI_CONV2_F32: WM_TRY(launch_gemm<EPI_CONV2_F32>(p, tile, pipe128, grid, st)); break;
+        case EPI_QKV_ENC: WM_TRY(launch_gemm<EPI_QKV_ENC>(p, tile, pipe128, grid, st)); break;
+        case EPI_XKV: WM_TRY(launch_gemm<EPI_XKV>(p, tile, pipe128, grid, st)); break;
+        case EPI_F32: WM_TRY(launch_gemm<EPI_F32>(p, tile, pipe128, grid, st)); break;
         default: wm_set_error("gemm: bad epilogue %d", g.epi); return WM_ERR_INVALID;
     }
     WM_HIP(hipGetLastError());

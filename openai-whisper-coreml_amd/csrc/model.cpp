@@ -87,6 +87,7 @@ void wm_model_drop_graphs(WmModel *m) {
     for (WmModel::GraphSet &g : m->graph_sets) g.destroy();
     m->graph_sets.clear();
     m->graph_cur = -1;
+    m->lid_graph.destroy();
 }
 
 WmTsDev wm_model_ts_dev(const WmModel *m) {

@@ -176,6 +176,20 @@ struct WmModel {
         }
         unsigned long stamp = 0;   // last use (LRU eviction)
     };
+    // The ONE decoder step of a language-identification call (Whisper.swift:33-40: <|startoftranscript|> -> arg-max over the
+    // language ids): ~100 launches of 3-5 us each, i.e. as long on the host (eager: ~3.5 us per launch) as on the GPU --
+    // captured once per shape and replayed (round 6: the reference's own flow, device-resident, 2.23 -> see profiles/).
+    struct LidGraph {
+        int B = 0, cap_b = 0, first = 0, last = 0, logits = 0;
+        hipGraph_t g = nullptr;
+        hipGraphExec_t e = nullptr;
+        void destroy() {
+            if (e) (void)hipGraphExecDestroy(e);
+            if (g) (void)hipGraphDestroy(g);
+            e = nullptr; g = nullptr; B = 0;
+        }
+    } lid_graph;
+    std::vector<int32_t> lid_host;   // host staging of the call's <|startoftranscript|> row (outlives the async upload)
     static constexpr int kMaxGraphSets = 4;
     std::vector<GraphSet> graph_sets;
     int graph_cur = -1;            // the set of the decode being enqueued

@@ -281,15 +281,44 @@ static int detect_language_impl(wm_ctx *ctx, const float *xa, int B, int32_t sot
     WM_REQUIRE(sot >= 0 && sot < V && lang_first >= 0 && lang_first <= lang_last && lang_last < V, WM_ERR_INVALID,
                "token ids outside the vocabulary (n_vocab = %d)", V);
     WM_TRY(wm_model_decode_begin(ctx, B));
+    // (round 6: one stream, no host synchronisation until the result is wanted -- the <|startoftranscript|> row is staged in
+    // a buffer that outlives the call, uploaded FIRST, and the features' K/V GEMMs + the decoder step are enqueued behind it)
+    m->lid_host.assign(B, sot);  // Whisper.swift:34-35
+    WM_HIP(hipMemcpyAsync(m->dseq, m->lid_host.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
     WM_TRY(load_xa(ctx, xa, B, mem));
-    std::vector<int32_t> sots(B, sot);  // Whisper.swift:34-35
-    WM_HIP(hipMemcpyAsync(m->dseq, sots.data(), (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
-    WM_HIP(hipStreamSynchronize(ctx->stream));                              // fences `sots`
     WM_TRY(wm_model_set_pos(ctx, 0));
     WM_TRY(wm_model_embed_first(ctx, B));
-    WM_TRY(wm_model_decode_step(ctx, B, probs != nullptr, lang_first, lang_last));     // :36-37
-    WM_TRY(wm_argmax_embed(ctx, m->dargmax, m->vpad / 16, B, nullptr, nullptr, 0, m->dresult, lang_first, nullptr,
-                           nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, m->darrive, lang_first));  // :38
+    static const bool no_graph = getenv("WM_NO_GRAPH") != nullptr;
+    auto step = [&]() -> int {
+        WM_TRY(wm_model_decode_step(ctx, B, probs != nullptr, lang_first, lang_last));     // :36-37
+        return wm_argmax_embed(ctx, m->dargmax, m->vpad / 16, B, nullptr, nullptr, 0, m->dresult, lang_first, nullptr,
+                               nullptr, 0, 0, nullptr, nullptr, nullptr, nullptr, m->darrive, lang_first);  // :38
+    };
+    if (no_graph || ctx->prof.on) {
+        WM_TRY(step());
+    } else {
+        WmModel::LidGraph &lg = m->lid_graph;
+        const int want = probs != nullptr ? 1 : 0;
+        if (!lg.e || lg.B != B || lg.cap_b != m->cap_b || lg.first != lang_first || lg.last != lang_last || lg.logits != want) {
+            lg.destroy();
+            WM_HIP(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            const int crc = step();
+            const hipError_t ce = hipStreamEndCapture(ctx->stream, &lg.g);
+            if (crc != WM_OK || ce != hipSuccess) {
+                if (ce == hipSuccess && lg.g) (void)hipGraphDestroy(lg.g);
+                lg.g = nullptr;
+                if (crc != WM_OK) return crc;
+                WM_HIP(ce);
+            }
+            if (hipGraphInstantiate(&lg.e, lg.g, nullptr, nullptr, 0) != hipSuccess) {
+                lg.destroy();
+                wm_set_error("hipGraphInstantiate failed for the language-identification step");
+                return WM_ERR_HIP;
+            }
+            lg.B = B; lg.cap_b = m->cap_b; lg.first = lang_first; lg.last = lang_last; lg.logits = want;
+        }
+        WM_HIP(hipGraphLaunch(lg.e, ctx->stream));
+    }
     if (probs) {  // openai-whisper detect_language(): softmax over the language-token logits only
         const int n_lang = lang_last - lang_first + 1;
         float *d_probs = probs;
@@ -302,13 +331,12 @@ static int detect_language_impl(wm_ctx *ctx, const float *xa, int B, int32_t sot
         if (mem == WM_MEM_HOST)
             WM_HIP(hipMemcpyAsync(probs, d_probs, (size_t)B * n_lang * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
-    std::vector<int32_t> res(B);
-    WM_HIP(hipMemcpyAsync(res.data(), m->dresult, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-    WM_HIP(hipStreamSynchronize(ctx->stream));
-    if (mem == WM_MEM_DEVICE) {
-        WM_HIP(hipMemcpy(lang_idx, res.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+    if (mem == WM_MEM_DEVICE) {   // the caller's buffer is device memory: one device-to-device copy behind the step
+        WM_HIP(hipMemcpyAsync(lang_idx, m->dresult, (size_t)B * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        WM_HIP(hipStreamSynchronize(ctx->stream));
     } else {
-        memcpy(lang_idx, res.data(), (size_t)B * 4);
+        WM_HIP(hipMemcpyAsync(lang_idx, m->dresult, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+        WM_HIP(hipStreamSynchronize(ctx->stream));
     }
     return WM_OK;
 }

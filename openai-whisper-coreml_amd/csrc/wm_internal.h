@@ -106,6 +106,7 @@ struct WmFrontend {
     int *band_start[2] = {nullptr, nullptr};
     int *band_len[2] = {nullptr, nullptr};
     float *band_w[2] = {nullptr, nullptr};  // [n_mels][WM_MEL_MAXW]
+    int band_maxw[2] = {0, 0};              // widest band of the filterbank (the LDS-resident copy of the f32 kernel holds 16)
     void *gmax = nullptr;                   // per-chunk encoded maxima (u64 per chunk)
     int gmax_cap = 0;
     void *scratch = nullptr;                // staging for host-pointer calls
@@ -183,6 +184,7 @@ struct WmTuning {
     int xattn_splits = 0;         // force the split count of the cross-attention (1, 2, 4, 8)
     int gemm_tile = 0;            // force the encoder GEMM tile (128 / 256)
     int gemm_gm = 4;              // grouped tile order of the encoder GEMM
+    int gemm128_pipe = 0;         // PROBE: the 128 x 128 tile's 3-stage pipeline kernel: 0 = the rule (grids <= 2 rounds of the chip), 1 = never, 2 = always
     int no_early_stop = 0;        // 1: decode every position and truncate on the host (the round-2 behaviour)
     int logits_tn = 0;            // 1 / 2: tiles per workgroup of the logits product at <= 16 rows (product: 4)
     int enc_attn_mfma_sum = 0;    // 1: encoder attention row sums by a ones-operand MFMA instead of f32 VALU adds

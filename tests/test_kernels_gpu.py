@@ -249,6 +249,7 @@ def test_gemm_256_tile_is_bitwise_equal_to_the_128_tile(ctx):
     synchronisation bug, not rounding.
     (tools/gpu_gemm_race_screen.py is the long version: 1080 comparisons next to a running bench, 0 mismatches.)"""
     ctx.lib.wmdbg_set_gemm_tile.argtypes = [ctypes.c_int]
+    ctx.lib.wmdbg_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
     try:
         for it in range(3):
             for (M, N, K) in [(2048, 2048, 1280), (1031, 768, 448), (1536, 1280, 5120)]:
@@ -258,11 +259,14 @@ def test_gemm_256_tile_is_bitwise_equal_to_the_128_tile(ctx):
                 bias = rng.standard_normal(N).astype(np.float32)
                 for epi in (6, 1, 2):
                     outs = []
-                    for tile in (128, 256, 64):
+                    # 128: the double-buffer kernel (pipe 1) and the 3-stage pipeline of round 6 (pipe 2); 256; 64
+                    for tile, pipe in ((128, 1), (256, 0), (64, 0), (128, 2)):
                         assert ctx.lib.wmdbg_set_gemm_tile(tile) == 0
+                        assert ctx.lib.wmdbg_set_tuning(b"gemm128_pipe", pipe) == 0
                         C = np.full((M, N), 0.25, np.float32)
                         assert ctx.lib.wmdbg_gemm(ctx.handle, P(A), P(Wt), P(bias), P(C), M, N, K, epi) == 0
                         outs.append(C)
-                    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), (it, M, N, K, epi)
+                    for o in outs[1:]:
+                        assert np.array_equal(outs[0], o), (it, M, N, K, epi)
     finally:
         ctx.lib.wmdbg_set_gemm_tile(0)

@@ -223,8 +223,11 @@ def test_whole_model_256_tile_is_bitwise_equal_to_the_128_tile(pkg):
         mel = ctx.logmel(pcm, out_dtype=np.float32)
         toks = np.array([[1, 7, 300, 1023], [4, 4, 900, 17], [9, 2, 2, 511]], np.int32)
         outs = []
-        for tile in (128, 256, 64, 0):    # 64: the single-chunk tile of round 6; 0: the product's own choice per product
+        ctx.lib.wmdbg_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        # 64: the single-chunk tile of round 6; (128, pipe 2): the 3-stage pipeline of the 128 tile; 0: the product's own choice
+        for tile, pipe in ((128, 1), (256, 0), (64, 0), (128, 2), (0, 0)):
             assert ctx.lib.wmdbg_set_gemm_tile(tile) == 0
+            assert ctx.lib.wmdbg_set_tuning(b"gemm128_pipe", pipe) == 0
             xa = ctx.encode_mel(mel)
             lg = ctx.decode_logits(toks, xa)
             gen, lens = ctx.transcribe_greedy(pcm, [1, 2], 6)
@@ -235,6 +238,7 @@ def test_whole_model_256_tile_is_bitwise_equal_to_the_128_tile(pkg):
                 assert np.array_equal(a, b)
     finally:
         ctx.lib.wmdbg_set_gemm_tile(0)
+        ctx.lib.wmdbg_set_tuning(b"reset", 0)
         ctx.close()
 
 
