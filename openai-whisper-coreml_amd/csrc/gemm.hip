@@ -54,6 +54,27 @@ __device__ __forceinline__ float gelu_erf(float x) {
     const float h = 0.5f * t * poly * __builtin_amdgcn_exp2f(-(z * z) * 1.4426950408889634f);
     return x * (x < 0.f ? h : 1.0f - h);
 }
+// The same function on TWO values at once (round 6): every full-rate operation as a packed-f32 instruction (v_pk_mul_f32 /
+// v_pk_fma_f32 / v_pk_add_f32: two lanes' worth of work per issue slot), the two quarter-rate ones (v_rcp_f32, v_exp_f32) and the
+// select per value.  Operation for operation the sequence of gelu_erf above, IEEE per component: the same bits (the tile
+// shapes' epilogues mix the two forms; the bitwise tile tests hold them together).  The fc1 epilogue is VALU work with the
+// matrix pipe idle (profiles/r06_pmc_encoder_stalls.txt: ~36 % of a 256 x 256 tile's time).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    const f32x2 z = ax * (f32x2){0.70710678118654752440f, 0.70710678118654752440f};
+    const f32x2 den = __builtin_elementwise_fma((f32x2){0.3275911f, 0.3275911f}, z, (f32x2){1.0f, 1.0f});
+    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    f32x2 poly = __builtin_elementwise_fma(t, (f32x2){1.061405429f, 1.061405429f}, (f32x2){-1.453152027f, -1.453152027f});
+    poly = __builtin_elementwise_fma(t, poly, (f32x2){1.421413741f, 1.421413741f});
+    poly = __builtin_elementwise_fma(t, poly, (f32x2){-0.284496736f, -0.284496736f});
+    poly = __builtin_elementwise_fma(t, poly, (f32x2){0.254829592f, 0.254829592f});
+    const f32x2 e = -(z * z) * (f32x2){1.4426950408889634f, 1.4426950408889634f};
+    const f32x2 ex = {__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+    const f32x2 h = (f32x2){0.5f, 0.5f} * t * poly * ex;
+    const f32x2 g = {x.x < 0.f ? h.x : 1.0f - h.x, x.y < 0.f ? h.y : 1.0f - h.y};
+    return x * g;
+}
 // f32 -> bf16, round to nearest even: v_cvt_pk_bf16_f32 on gfx950
 __device__ __forceinline__ bf16_t f2bf(float f) {
     const __bf16 h = (__bf16)f;
@@ -203,11 +224,12 @@ __device__ __forceinline__ void store_tile_staged(const GemmDev &p, const f32x4 
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[ps * 4 + ii][j][r] + bv[j];
-                    if (EPI == EPI_GELU_BF16) v = gelu_erf(v);
-                    if (EPI == EPI_QKV_ENC && qpart) v = v * WM_ENC_QSCALE;   // wave-uniform: the query third, see model.h
-                    *(bf16_t *)(L + (ii * 16 + fq * 4 + r) * STAGE_ROW_BYTES + (j * 16 + frow) * 2) = f2bf(v);
+                for (int r = 0; r < 4; r += 2) {
+                    f32x2 v = {acc[ps * 4 + ii][j][r] + bv[j], acc[ps * 4 + ii][j][r + 1] + bv[j]};
+                    if (EPI == EPI_GELU_BF16) v = gelu_erf2(v);
+                    if (EPI == EPI_QKV_ENC && qpart) v = v * (f32x2){WM_ENC_QSCALE, WM_ENC_QSCALE};   // wave-uniform: the query third, see model.h
+                    *(bf16_t *)(L + (ii * 16 + fq * 4 + r) * STAGE_ROW_BYTES + (j * 16 + frow) * 2) = f2bf(v.x);
+                    *(bf16_t *)(L + (ii * 16 + fq * 4 + r + 1) * STAGE_ROW_BYTES + (j * 16 + frow) * 2) = f2bf(v.y);
                 }
         // row -> (batch, row-in-batch): ONE division per pass (the lane's first row), then 8 rows further per step
         // (16 divisions per lane per tile were ~1 us of the epilogue; rows-per-batch >= 8 is checked by the caller)
