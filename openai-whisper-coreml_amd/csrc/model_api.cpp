@@ -652,7 +652,23 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
     const bool explicit_lanes = ctx->max_lanes > 0;
     const int L = ctx->prof.on ? 1 : (explicit_lanes ? ctx->max_lanes : lane_limit());
     const int solo = g_wm_tuning.lane_solo_cus;   // probes only (0 in the product)
-    const int parts = (ctx->prof.on || solo) ? 0 : wm_lane_parts(B, L, explicit_lanes, D.n_text_state, D.n_text_layer);
+    int parts = (ctx->prof.on || solo || ctx->no_cu_masks) ? 0 : wm_lane_parts(B, L, explicit_lanes, D.n_text_state, D.n_text_layer);
+    if (parts) {
+        // the sub-chip lanes of this partition, created on first use.  A device / driver that refuses CU-masked streams (a
+        // partitioned GPU, an older KFD) is not an error: the call falls back to the unmasked policy, once and for all
+        std::vector<wm_ctx *> &pl = ctx->part_lanes[parts - 2];
+        while ((int)pl.size() < parts) {
+            wm_ctx *c = nullptr;
+            const int k = (int)pl.size();
+            if (wm_clone_cus(ctx, k * 32 / parts, (k + 1) * 32 / parts, &c) != WM_OK) {   // 16 + 16, or 10 + 11 + 11 CUs of every XCD
+                ctx->no_cu_masks = true;
+                parts = 0;
+                break;
+            }
+            pl.push_back(c);
+        }
+        WM_TRY(wm_ctx_make_current(ctx));
+    }
     const int G = parts ? parts : wm_group_count(B, L, explicit_lanes, g_wm_tuning.group_chunks);
     const int n_lanes = solo ? 1 : (parts ? parts : (G < L ? G : L));
     wm_ctx *solo_ctx = nullptr;
@@ -661,15 +677,7 @@ extern "C" int wm_transcribe_greedy(wm_ctx *ctx, const void *pcm, wm_dtype pcm_d
         wm_ctx *&c = ctx->solo_lanes[solo];
         if (!c) WM_TRY(wm_clone_cus(ctx, 0, solo, &c));
         solo_ctx = c;
-    } else if (parts) {
-        std::vector<wm_ctx *> &pl = ctx->part_lanes[parts - 2];
-        while ((int)pl.size() < parts) {
-            wm_ctx *c = nullptr;
-            const int k = (int)pl.size();
-            WM_TRY(wm_clone_cus(ctx, k * 32 / parts, (k + 1) * 32 / parts, &c));   // 16 + 16, or 10 + 11 + 11 CUs of every XCD
-            pl.push_back(c);
-        }
-    } else {
+    } else if (!parts) {
         while ((int)ctx->lanes.size() < n_lanes - 1) {
             wm_ctx *c = nullptr;
             WM_TRY(wm_clone(ctx, &c));

@@ -153,6 +153,7 @@ struct wm_ctx {
     // all 256 CUs with every launch and serialising at the CU level (model_api.cpp, the group policy).
     int n_cus = 256, cu_lo = 0, cu_hi = 32;   // the CUs [cu_lo, cu_hi) of every XCD
     std::vector<wm_ctx *> part_lanes[2];   // [0]: the two clones of the 2-way partition, [1]: the three of the 3-way one (created on first use)
+    bool no_cu_masks = false;              // a CU-masked stream could not be created on this device: the policy stays unmasked
     std::map<int, wm_ctx *> solo_lanes;    // probes (debug knob lane_solo_cus): a clone confined to the first n CUs of every XCD
 };
 // weight-sharing clone of `parent` whose stream is confined to the CUs [cu_lo, cu_hi) of every XCD (api.cpp)

@@ -6,7 +6,9 @@ whole call (front end + encoder + 224-token decode), min of 2 after a warm-up, f
     split=P     P groups of ceil(B / P) chunks on P UNMASKED lanes (= gc=ceil(B / P))
     product     the product's own rule (no knob)
 
-    python tools/gpu_group_policy_probe.py [model] [B,B,...] [col,col,...]
+    python tools/gpu_group_policy_probe.py [model] [B,B,...] [col,col,...] [earlystop]
+earlystop: every chunk gets a token budget of uniform(40..200) (seeded; wm_set_token_budgets) instead of the fixed 224 tokens --
+a group runs until its LAST row is finished, so smaller groups stop earlier (the default policy was measured at fixed length).
 Every column's tokens are compared with the first column's ('!' = differ: a launch-shape choice must never change a token)."""
 import ctypes
 import os
@@ -25,6 +27,7 @@ def main():
     model = sys.argv[1] if len(sys.argv) > 1 else "large-v2"
     sizes = [int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "9,12,15,16,20,24,32,48").split(",")]
     cols = (sys.argv[3] if len(sys.argv) > 3 else "gc=8,gc=128,parts=2,parts=3,product").split(",")
+    early = len(sys.argv) > 4 and sys.argv[4] == "earlystop"
     lib = B.load_debug_library()
     lib.wmdbg_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
     lib.wmdbg_set_tuning(b"reset", 0)
@@ -38,7 +41,8 @@ def main():
     ctx.finalize()
     dp = ctx.to_device(pcm)
 
-    print("%s: audio-s/s of one call of B chunks by group policy (3 lanes available)" % model)
+    print("%s: audio-s/s of one call of B chunks by group policy (3 lanes available)%s" % (
+        model, "; EARLY STOP: per-chunk token budgets uniform(40..200)" if early else ""))
     print("B    " + "".join("%-13s" % c for c in cols))
     for nb in sizes:
         row, ref = "%-4d " % nb, None
@@ -58,7 +62,8 @@ def main():
             best = None
             for i in range(3):
                 t0 = time.perf_counter()
-                toks, _ = ctx.transcribe_greedy(dp, prompt, 224, eot=-1, mem=B.WM_MEM_DEVICE, pcm_dtype=B.WM_I16, B=nb)
+                bud = np.random.default_rng(4000 + nb).integers(40, 201, size=nb) if early else None
+                toks, _ = ctx.transcribe_greedy(dp, prompt, 224, eot=-1, mem=B.WM_MEM_DEVICE, pcm_dtype=B.WM_I16, B=nb, budgets=bud)
                 dt = time.perf_counter() - t0
                 if i and (best is None or dt < best):
                     best = dt

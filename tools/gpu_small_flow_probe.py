@@ -2,7 +2,8 @@
 arg-max; ContentView.swift:56-63, Whisper.swift:23-40) DEVICE-RESIDENT, split into its three calls: wall ms of each
 (min of 10 after a warm-up, each call synchronised) and of the three back to back.
 
-    python tools/gpu_small_flow_probe.py [model=small]"""
+    python tools/gpu_small_flow_probe.py [model=small] [knob=value ...]   (knobs: wmdbg_set_tuning, debug library)"""
+import ctypes
 import os
 import sys
 import time
@@ -16,9 +17,17 @@ B = pkg.binding
 
 
 def main():
-    model = sys.argv[1] if len(sys.argv) > 1 else "small"
+    knobs = [a for a in sys.argv[1:] if "=" in a]
+    pos = [a for a in sys.argv[1:] if "=" not in a]
+    model = pos[0] if pos else "small"
     dims = B.MODEL_DIMS[model]
-    c = B.Context(dims)
+    c = B.Context(dims, debug=bool(knobs))
+    if knobs:
+        c.lib.wmdbg_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        for kv in knobs:
+            k, v = kv.split("=")
+            assert c.lib.wmdbg_set_tuning(k.encode(), int(v)) == 0, kv
+        print("knobs:", " ".join(knobs))
     c.init_synthetic(20240928)
     c.finalize()
     rng = np.random.default_rng(2)
