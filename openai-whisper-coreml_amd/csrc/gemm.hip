@@ -903,13 +903,15 @@ int wm_gemm(wm_ctx *ctx, const GemmArgs &g) {
     p.M = g.M; p.N = g.N; p.K = g.K; p.pos = g.pos; p.vt = g.vt;
     p.d_model = g.d_model; p.n_head = g.n_head; p.seq = g.seq; p.seq_pad = g.seq_pad; p.batch = g.batch;
     // Tile choice: the 256 x 256 staggered-phase kernel once it can put a workgroup on most CUs (one per CU); the 128 x 128
-    // kernel (two per CU) below that; the 64 x 64 kernel when even 128 x 128 tiles leave most of the chip idle (fewer than 160
+    // kernel (two per CU) below that; the 64 x 64 kernel when even 128 x 128 tiles leave most of the chip idle (fewer than 128
     // tiles: one 30 s chunk at N = d -- small: 72 -> 288 workgroups; the 128 tile keeps products whose 128-grid fills the chip).
     // (g_wm_tuning.gemm_tile: the debug library's tests / probes.)
     const int env_tile = g_wm_tuning.gemm_tile;
     const long tiles256 = (long)((g.M + BM2 - 1) / BM2) * ((g.N + BN2 - 1) / BN2);
     const long tiles128 = (long)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    int tile = (g.K >= 2 * BK && tiles256 >= 160) ? 256 : (tiles128 >= 160 ? 128 : 64);
+    // (128 .. 159 tiles of 128 x 128 run on the pipelined 128 kernel, one per CU: Whisper-small's cross-K/V products at one chunk,
+    // 144 tiles, 0.679 -> 0.632 ms per language-identification call against 576 tiles of 64 x 64; 72 tiles: the 64 tile wins)
+    int tile = (g.K >= 2 * BK && tiles256 >= 160) ? 256 : (tiles128 >= 128 ? 128 : 64);
     if (env_tile == 64 || env_tile == 128) tile = env_tile;
     if (env_tile == 256 && g.K >= 2 * BK) tile = 256;
     const int bm = tile == 256 ? BM2 : tile == 128 ? BM : BM3, bn = tile == 256 ? BN2 : tile == 128 ? BN : BN3;
