@@ -1830,3 +1830,49 @@ def test_context_lifecycle_returns_device_memory(pkg):
         assert np.array_equal(again[0], first[0]) and np.array_equal(again[1], first[1])
         lost = base - _hip_free_bytes()
         assert lost <= (8 << 20), "cycle %d: %.1f MiB of device memory not returned" % (i + 2, lost / 2**20)
+
+
+def test_sub_chip_lanes_carry_the_decode_policy_state(pkg):
+    """Round 6: the product policy runs a 24 .. 128-chunk call of a NARROW model (decoder width <= 512) as two decode groups on
+    CU-masked half-chip lanes (wm_lane_parts) -- weight-sharing clones created on first use.  Whatever state a call depends on
+    must reach them: suppress lists and timestamp rules set BEFORE the lanes exist (copied at clone time) and changed AFTER
+    (propagated by wm_set_suppress / wm_set_timestamp_rules), a stop token, per-chunk budgets.  Base width, 2 + 2 layers, 40
+    chunks: every variant's tokens and lengths on the masked lanes (default policy) == ONE group on the context's own stream
+    (wm_set_lanes(1)), bit for bit; the debug policy hook confirms the call is a two-part one."""
+    dims = dict(pkg.binding.MODEL_DIMS["base"], n_audio_layer=2, n_text_layer=2)
+    lib = pkg.binding.load_debug_library()
+    assert lib.wmdbg_lane_parts(40, 3, 0, dims["n_text_state"]) == 2
+    ctx = pkg.binding.Context(dims)
+    ctx.init_synthetic(77, matrix_gain=W.lively_gain(dims))
+    _perturb_ln_on_device(ctx, dims, seed=4)
+    ctx.finalize()
+    pcm = np.stack([tone_chunk(i) if i % 3 else L.synth_chunk(900 + i) for i in range(40)])
+    prompt = [50258, 50259, 50359]
+    TS, EOT, NEW = 50364, 50257, 40
+    specials = list(range(50258, 50364))
+
+    def both(**kw):
+        ctx.set_lanes(0)
+        a = ctx.transcribe_greedy(pcm, prompt, NEW, **kw)
+        ctx.set_lanes(1)
+        b = ctx.transcribe_greedy(pcm, prompt, NEW, **kw)
+        ctx.set_lanes(0)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        return a
+    # 1. rules set before the masked lanes exist
+    ctx.set_suppress(specials, [EOT])
+    ctx.set_timestamp_rules(True, TS, EOT, 50)
+    t1, _ = both()
+    assert np.all(t1[:, 0] >= TS) and not (set(t1.ravel().tolist()) & set(specials))
+    # 2. rules CHANGED after they exist: another suppress list, timestamps off; a stop token that does occur; budgets
+    ctx.set_timestamp_rules(False, TS, EOT, 50)
+    ctx.set_suppress(specials + [int(t1[0, 3])], [])
+    t2, _ = both()
+    assert not np.array_equal(t1, t2) and int(t1[0, 3]) not in set(t2.ravel().tolist())
+    stop_tok = int(np.bincount(t2[:, 4:].ravel()).argmax())
+    bud = [int(b) for b in np.random.default_rng(3).integers(5, NEW + 1, size=40)]
+    t3, l3 = both(eot=stop_tok, budgets=bud)
+    assert l3.min() < NEW and len({r.tobytes() for r in t2}) >= 30
+    for i in range(40):
+        assert np.array_equal(t3[i, :l3[i]], t2[i, :l3[i]])          # early stop == decode everything and truncate
+    ctx.close()
