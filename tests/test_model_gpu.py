@@ -1876,3 +1876,16 @@ def test_sub_chip_lanes_carry_the_decode_policy_state(pkg):
     for i in range(40):
         assert np.array_equal(t3[i, :l3[i]], t2[i, :l3[i]])          # early stop == decode everything and truncate
     ctx.close()
+
+
+def test_masked_lane_soak_alternating_shapes(pkg):
+    """tools/gpu_masked_lane_soak.py as a test: base at full depth, 40 calls of 8 .. 72 chunks in random order through the
+    product policy (two CU-masked half-chip groups from 24 chunks, one group below), early stop on / off at random -- every
+    result equals the single-group reference decoded once per (size, stop mode).  What a one-shot test cannot see: graph
+    re-use across alternating shapes on the masked lanes, state left over from a call of another size."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_masked_lane_soak.py"), "40", "base"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
